@@ -1,0 +1,132 @@
+/*
+ * kangaroo_hip.h -- C ABI of libkangaroo_hip.so, the MI355X (gfx950) kangaroo jump engine.
+ *
+ * This is the drop-in boundary for ONE hot path of JeanLucPons/Kangaroo: the per-herd random
+ * walk that the reference implements in GPU/GPUEngine.cu + GPU/GPUCompute.h + GPU/GPUMath.h
+ * behind `class GPUEngine` (GPU/GPUEngine.h:40-84).  Every entry point below names the
+ * reference interface it replaces (file:line relative to the reference root).  The C++ class
+ * `GPUEngine` with the reference's exact public surface is re-created over this ABI in
+ * kangaroo_amd/host/GPUEngine.{h,cpp}; INTEGRATION.md shows how the unmodified reference
+ * host code links against it.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all big integers are little-endian uint64_t limbs:
+ *     field elements / x / y = 4 limbs, device distances = 2 limbs (128 bit, GPUMath.h:119-121).
+ *   - kangaroo index kIdx = position in the arrays given to kng_set_kangaroos
+ *     (= ITEM.kIdx of GPUEngine.h:34-38; type = kIdx & 1, GPUEngine.cu:409).
+ *   - distances at this level are DEVICE distances: the caller has already added the wild
+ *     offset mod n for odd kIdx (GPUEngine.cu:406-411) and removes it again from what
+ *     kng_drain / kng_get_kangaroos return (GPUEngine.cu:477,672).  The C++ class does that.
+ *   - every function returns KNG_OK (0) or a negative KNG_E* code; kng_last_error() gives text.
+ *     Nothing falls back to the CPU: without a usable gfx950 device kng_create fails.
+ *   - one host thread per engine handle; distinct handles may be driven concurrently
+ *     (one per GPU, Kangaroo.cpp:1041-1047).  Every entry point selects its own device.
+ */
+#ifndef KANGAROO_HIP_H
+#define KANGAROO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KNG_NB_JUMP 32   /* Constants.h:29  NB_JUMP                                    */
+#define KNG_NB_RUN 64    /* Constants.h:35  NB_RUN: jumps per kangaroo per launch       */
+#define KNG_GRP_SIZE 128 /* Constants.h:32  GPU_GRP_SIZE: herd = gridX*gridY*128         */
+
+#define KNG_OK 0
+#define KNG_E_NODEVICE (-1) /* no HIP device / bad device id (GPUEngine.cu:152-169)      */
+#define KNG_E_ALLOC (-2)    /* device or pinned allocation failed (GPUEngine.cu:201-232) */
+#define KNG_E_ARG (-3)      /* bad argument                                              */
+#define KNG_E_STATE (-4)    /* call sequence error (e.g. launch before set_params)       */
+#define KNG_E_HIP (-5)      /* HIP runtime error, see kng_last_error()                   */
+
+typedef struct kng_engine kng_engine; /* opaque; replaces the private state of GPUEngine.h:66-82 */
+
+/* One distinguished point; replaces the 56-byte device record of GPUMath.h:173-188 and the
+ * host ITEM of GPUEngine.h:34-38 (d is still the DEVICE distance here). */
+typedef struct {
+    uint64_t x[4];
+    uint64_t d[2];
+    uint64_t kidx;
+} kng_item;
+
+/* ---- device discovery: GPUEngine.cu:280-308 (GetGridSize), :329-375 (PrintCudaInfo) -------- */
+int kng_device_count(void);
+/* name (<= name_cap bytes incl. NUL), compute units, total memory, gcn arch string */
+int kng_device_info(int dev, char *name, size_t name_cap, int *cu_count, uint64_t *mem_bytes,
+                    char *arch, size_t arch_cap);
+/* fills *x / *y when <= 0 with the reference's defaults: x = 2*CU count, y = 128
+ * (GPUEngine.cu:299-303; the per-SM core table has no AMD entry, so y falls back to 128) */
+int kng_default_grid(int dev, int *x, int *y);
+
+/* ---- lifetime: GPUEngine ctor/dtor, GPUEngine.cu:144-263 ------------------------------------ */
+/* herd size = grid_x*grid_y*128 kangaroos; max_found = DP capacity per launch (Kangaroo.cpp:523) */
+int kng_create(int dev, int grid_x, int grid_y, uint32_t max_found, kng_engine **out);
+void kng_destroy(kng_engine *h); /* safe while a launch is in flight (Kangaroo.cpp:572-634) */
+
+uint64_t kng_nb_kangaroos(const kng_engine *h); /* GetNbThread()*GetGroupSize(), GPUEngine.cu:377 */
+uint64_t kng_memory_bytes(const kng_engine *h); /* GetMemory(), GPUEngine.cu:266-268 (64-bit)  */
+
+/* ---- parameters: SetParams, GPUEngine.cu:559-590 ---------------------------------------------- */
+/* jd: [32][2], jx/jy: [32][4] limbs */
+int kng_set_params(kng_engine *h, uint64_t dp_mask, const uint64_t *jd, const uint64_t *jx,
+                   const uint64_t *jy);
+
+/* ---- herd state: SetKangaroos/GetKangaroos/SetKangaroo, GPUEngine.cu:381-538 ---------------- */
+/* x,y: n x 4 limbs; d: n x 2 limbs; strides in uint64_t units between consecutive kangaroos
+ * (4,4,2 for packed arrays; 5,5,5 when pointing into an array of reference `Int`). n must
+ * equal kng_nb_kangaroos(). */
+int kng_set_kangaroos(kng_engine *h, const uint64_t *x, size_t xs, const uint64_t *y, size_t ys,
+                      const uint64_t *d, size_t ds, uint64_t n);
+/* waits for an in-flight launch, then returns the state it left (GPUEngine.cu:452 blocks the
+ * same way through the null stream) */
+int kng_get_kangaroos(kng_engine *h, uint64_t *x, size_t xs, uint64_t *y, size_t ys, uint64_t *d,
+                      size_t ds, uint64_t n);
+/* overwrite one kangaroo; stream-ordered after an in-flight launch, never blocks the host
+ * (the reference issues ten blocking 8-byte copies, GPUEngine.cu:504-530) */
+int kng_set_kangaroo(kng_engine *h, uint64_t kidx, const uint64_t x[4], const uint64_t y[4],
+                     const uint64_t d[2]);
+
+/* ---- the hot path: callKernel / Launch, GPUEngine.cu:540-557, :607-679 ------------------------ */
+/* start KNG_NB_RUN jumps for every kangaroo, asynchronously.  At most one launch may be
+ * outstanding (not yet waited for). */
+int kng_launch(kng_engine *h);
+/* block until the outstanding launch has finished.  spin != 0 busy-waits, otherwise the host
+ * thread sleeps on the completion event (the reference polls with 1 ms sleeps, :621-629). */
+int kng_wait(kng_engine *h, int spin);
+/* copy out the distinguished points of the most recently WAITED launch.  *n_items = number
+ * stored (<= cap and <= max_found), *n_lost = points dropped because max_found was exceeded
+ * (GPUEngine.cu:641-648).  May be called while the next launch is already running: DP buffers
+ * are double-buffered. */
+int kng_drain(kng_engine *h, kng_item *items, uint32_t cap, uint32_t *n_items, uint32_t *n_lost);
+
+/* ---- measurement (new; the reference only has the host-side MK/s average, Thread.cpp:254-300) */
+/* HIP-event duration (ms) of the walk kernel of the most recently waited launch, measured on
+ * the stream the kernel ran on. */
+int kng_last_kernel_ms(const kng_engine *h, float *ms);
+/* tuning knobs, must be set before kng_set_kangaroos:
+ *   "group"  kangaroos walked per lane (batch size of the Montgomery inverse), power of two
+ *   "block"  threads per workgroup (multiple of 64)
+ *   "steps"  jumps per launch (default KNG_NB_RUN; only tests change it)
+ * kng_get_option reads them back (also "lanes", "waves_per_cu"). */
+int kng_set_option(kng_engine *h, const char *key, int64_t value);
+int kng_get_option(const kng_engine *h, const char *key, int64_t *value);
+
+/* ---- device self-test of the 256-bit primitives (replaces the compiled-out GPU_CHECK kernel,
+ *      GPUEngine.cu:43-92): r[i] = op(a[i], b[i]) on the GPU, n x 4 limbs each ----------------- */
+#define KNG_OP_MODMUL 0 /* GPUMath.h:810-858  */
+#define KNG_OP_MODSQR 1 /* GPUMath.h:909-1019 */
+#define KNG_OP_MODSUB 2 /* GPUMath.h:476-494  */
+#define KNG_OP_MODINV 3 /* GPUMath.h:700-803  */
+int kng_test_fieldop(int dev, int op, const uint64_t *a, const uint64_t *b, uint64_t *r, uint64_t n);
+
+const char *kng_last_error(void); /* thread-local text of the last failure */
+const char *kng_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KANGAROO_HIP_H */

@@ -1,0 +1,637 @@
+// kng_engine.hip -- MI355X (gfx950) kangaroo jump engine: walk kernel + C ABI (include/kangaroo_hip.h).
+//
+// Replaces, from scratch, the reference's GPU/GPUEngine.cu + GPU/GPUCompute.h + GPU/GPUMath.h.
+//
+// Design:
+//  * herd state lives in HBM as plane-major SoA of 16-byte vectors, indexed by kIdx:
+//        X01[N] X23[N] Y01[N] Y23[N] D[N]   (+ scratch product planes S01[N] S23[N])
+//    so that the 64 lanes of a wave read/write 1 KiB contiguous per instruction.
+//  * lane t of L lanes owns kangaroos {t, t+L, t+2L, ...} (G = N/L of them) and amortises ONE
+//    modular inversion over those G with Montgomery's trick, like the reference's 128 per
+//    thread (GPUMath.h:1166-1190) -- but the G states are streamed through HBM instead of
+//    living in 18 KB/lane of scratch ("local") memory.
+//  * one jump of the whole group is ONE pass: the pass that consumes the running inverse
+//    (backward over the previous pass's prefix products) also emits the prefix products of the
+//    next jump's dx in its own order, so passes alternate direction and each kangaroo's state is
+//    read once and written once per jump: 80 B in + 80 B out + 32 B product in + 32 B out.
+//  * the 32-entry jump table (GPUMath.h:51-54 __constant__) is staged in LDS, limb-major, so
+//    that the per-lane index x&31 hits 32 distinct bank pairs (conflict-free ds_read_b64).
+//  * distinguished points are compacted per wave (ballot + popcount prefix) with one atomic
+//    per wave and DP-bearing step instead of one per DP (GPUCompute.h:96-105).
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/kangaroo_hip.h"
+#include "kng_field.h"
+#include "kng_modinv.h"
+
+using namespace kng;
+
+// --------------------------------------------------------------------------------------------
+// device side
+// --------------------------------------------------------------------------------------------
+
+typedef ulonglong2 v16; // one 16-byte vector = two limbs
+
+struct DpRecord { // 64-byte device record: four aligned 16-byte stores
+    uint64_t x[4];
+    uint64_t d[2];
+    uint64_t kidx;
+    uint64_t pad;
+};
+
+struct WalkArgs {
+    v16 *x01, *x23, *y01, *y23, *d, *s01, *s23;
+    const uint64_t *jtab; // limb-major: jx[4][32] jy[4][32] jd[2][32]
+    uint64_t dp_mask;
+    uint32_t *dp_count;
+    DpRecord *dp_items;
+    uint32_t max_found;
+    uint32_t lanes; // L
+    uint32_t group; // G
+    uint32_t nsteps;
+};
+
+#define JT_JX 0
+#define JT_JY (4 * 32)
+#define JT_JD (8 * 32)
+#define JT_WORDS (10 * 32)
+
+KNG_DEV fe ld_fe(const v16 *p01, const v16 *p23, size_t i) {
+    const v16 a = p01[i], b = p23[i];
+    return fe{{a.x, a.y, b.x, b.y}};
+}
+KNG_DEV void st_fe(v16 *p01, v16 *p23, size_t i, const fe &v) {
+    p01[i] = make_ulonglong2(v.v[0], v.v[1]);
+    p23[i] = make_ulonglong2(v.v[2], v.v[3]);
+}
+KNG_DEV fe lds_fe(const uint64_t *tab, int base, uint32_t j) {
+    return fe{{tab[base + j], tab[base + 32 + j], tab[base + 64 + j], tab[base + 96 + j]}};
+}
+
+// wave64 compaction of distinguished points: one atomic per wave per DP-bearing step
+KNG_DEV void emit_dp(bool is_dp, const fe &x, const v16 &d, uint64_t kidx, const WalkArgs &a) {
+    const uint64_t m = __ballot(is_dp);
+    if (m == 0) return;
+    const uint32_t lane = __lane_id();
+    uint32_t base = 0;
+    const int leader = __ffsll((unsigned long long)m) - 1;
+    if ((int)lane == leader) base = atomicAdd(a.dp_count, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    if (is_dp) {
+        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
+        if (pos < a.max_found) {
+            v16 *rec = reinterpret_cast<v16 *>(&a.dp_items[pos]);
+            rec[0] = make_ulonglong2(x.v[0], x.v[1]);
+            rec[1] = make_ulonglong2(x.v[2], x.v[3]);
+            rec[2] = d;
+            rec[3] = make_ulonglong2(kidx, 0);
+        }
+    }
+}
+
+// The hot kernel.  Replaces comp_kangaroos/ComputeKangaroos (GPUEngine.cu:35-40, GPUCompute.h:22-117).
+__global__ void __launch_bounds__(256) kng_walk_kernel(const WalkArgs a) {
+    __shared__ uint64_t tab[JT_WORDS];
+    for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
+    __syncthreads();
+
+    const size_t L = a.lanes;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t G = a.group;
+    if (t >= L) return;
+
+    // pass 0: prefix products of dx in ascending order (GPUCompute.h:52-61 + GPUMath.h:1173-1177)
+    fe acc;
+    for (uint32_t g = 0; g < G; g++) {
+        const size_t idx = (size_t)g * L + t;
+        const fe x = ld_fe(a.x01, a.x23, idx);
+        const uint32_t j = (uint32_t)x.v[0] & (KNG_NB_JUMP - 1);
+        const fe dx = fe_sub(x, lds_fe(tab, JT_JX, j));
+        acc = g ? fe_mul(acc, dx) : dx;
+        st_fe(a.s01, a.s23, idx, acc);
+    }
+
+    for (uint32_t step = 0; step < a.nsteps; step++) {
+        // one inversion per lane per jump of the whole group (GPUMath.h:1179-1180)
+        fe inv = fe_inv(acc);
+        const bool backward = !(step & 1); // reverse of the pass that produced the products
+        const bool last = (step + 1 == a.nsteps);
+        // slot(k): kangaroo processed k-th in this pass
+        auto slot = [&](uint32_t k) -> size_t { return (size_t)(backward ? (G - 1 - k) : k) * L + t; };
+
+        size_t idx = slot(0);
+        fe cx = ld_fe(a.x01, a.x23, idx);
+        fe cy = ld_fe(a.y01, a.y23, idx);
+        v16 cd = a.d[idx];
+        fe nb = (G > 1) ? ld_fe(a.s01, a.s23, slot(1)) : fe_one();
+
+        for (uint32_t k = 0; k < G; k++) {
+            // ---- prefetch the next kangaroo and the product after it (before any store) ----
+            fe nx = cx, ny = cy, nnb = nb;
+            v16 nd = cd;
+            size_t nidx = idx;
+            if (k + 1 < G) {
+                nidx = slot(k + 1);
+                nx = ld_fe(a.x01, a.x23, nidx);
+                ny = ld_fe(a.y01, a.y23, nidx);
+                nd = a.d[nidx];
+            }
+            if (k + 2 < G) nnb = ld_fe(a.s01, a.s23, slot(k + 2));
+
+            // ---- this kangaroo: P += J[x & 31]   (GPUCompute.h:67-94) ----
+            const uint32_t j = (uint32_t)cx.v[0] & (KNG_NB_JUMP - 1);
+            const fe jx = lds_fe(tab, JT_JX, j);
+            const fe jy = lds_fe(tab, JT_JY, j);
+            const fe dx = fe_sub(cx, jx);
+            fe invk;
+            if (k + 1 < G) {
+                invk = fe_mul(inv, nb); // 1/dx      (GPUMath.h:1182-1186)
+                inv = fe_mul(inv, dx);  // 1/(product of the remaining dx)
+            } else {
+                invk = inv;
+            }
+            const fe dy = fe_sub(cy, jy);
+            const fe s = fe_mul(dy, invk);
+            const fe p2 = fe_sqr(s);
+            const fe rx = fe_sub(fe_sub(p2, jx), cx);
+            const fe ry = fe_sub(fe_mul(fe_sub(cx, rx), s), cy);
+            // d += jD[j]: raw 128-bit add (GPUMath.h:119-121)
+            {
+                const uint64_t jd0 = tab[JT_JD + j], jd1 = tab[JT_JD + 32 + j];
+                unsigned long long c = 0;
+                cd.x = __builtin_addcll(cd.x, jd0, 0, &c);
+                cd.y = cd.y + jd1 + c;
+            }
+            st_fe(a.x01, a.x23, idx, rx);
+            st_fe(a.y01, a.y23, idx, ry);
+            a.d[idx] = cd;
+
+            // ---- distinguished point? (GPUCompute.h:96-105) ----
+            emit_dp((rx.v[3] & a.dp_mask) == 0, rx, cd, (uint64_t)idx, a);
+
+            // ---- prefix product of the NEXT jump's dx, in this pass's order ----
+            if (!last) {
+                const uint32_t j2 = (uint32_t)rx.v[0] & (KNG_NB_JUMP - 1);
+                const fe dx2 = fe_sub(rx, lds_fe(tab, JT_JX, j2));
+                acc = k ? fe_mul(acc, dx2) : dx2;
+                st_fe(a.s01, a.s23, idx, acc);
+            }
+            cx = nx;
+            cy = ny;
+            cd = nd;
+            nb = nnb;
+            idx = nidx;
+        }
+    }
+}
+
+// overwrite one kangaroo, stream-ordered (replaces the ten 8-byte copies of GPUEngine.cu:504-530)
+__global__ void kng_patch_kernel(v16 *x01, v16 *x23, v16 *y01, v16 *y23, v16 *d, uint64_t idx, fe x,
+                                 fe y, v16 dd) {
+    st_fe(x01, x23, idx, x);
+    st_fe(y01, y23, idx, y);
+    d[idx] = dd;
+}
+
+// device self-test of the primitives (replaces the compiled-out check_gpu, GPUEngine.cu:43-92)
+__global__ void kng_fieldop_kernel(int op, const uint64_t *a, const uint64_t *b, uint64_t *r, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const fe x{{a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]}};
+    const fe y{{b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]}};
+    fe z;
+    switch (op) {
+    case KNG_OP_MODMUL: z = fe_mul(x, y); break;
+    case KNG_OP_MODSQR: z = fe_sqr(x); break;
+    case KNG_OP_MODSUB: z = fe_sub(x, y); break;
+    default: z = fe_inv(x); break;
+    }
+    for (int k = 0; k < 4; k++) r[4 * i + k] = z.v[k];
+}
+
+// --------------------------------------------------------------------------------------------
+// host side: the C ABI
+// --------------------------------------------------------------------------------------------
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(KNG_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));         \
+    } while (0)
+
+struct kng_engine {
+    int dev = 0;
+    int grid_x = 0, grid_y = 0;
+    uint64_t n = 0; // kangaroos
+    uint32_t max_found = 0;
+    // tuning
+    uint32_t group = 0; // kangaroos per lane
+    uint32_t block = 64;
+    uint32_t nsteps = KNG_NB_RUN;
+    uint32_t lanes = 0;
+    int cu_count = 0;
+    // device memory
+    v16 *planes = nullptr; // 7 planes of n v16
+    uint64_t *jtab = nullptr;
+    uint32_t *dp_count[2] = {nullptr, nullptr};
+    DpRecord *dp_items[2] = {nullptr, nullptr};
+    // pinned host memory
+    uint32_t *h_count[2] = {nullptr, nullptr};
+    DpRecord *h_items = nullptr;
+    v16 *h_stage = nullptr;
+    size_t stage_kang = 0;
+    // streams / events
+    hipStream_t walk = nullptr, copy = nullptr;
+    hipEvent_t ev_start[2] = {nullptr, nullptr}, ev_stop[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    // state
+    uint64_t dp_mask = 0;
+    bool have_params = false, have_herd = false;
+    bool outstanding = false; // launched, not yet waited
+    int slot_next = 0;        // DP buffer the next launch writes
+    int slot_ready = -1;      // DP buffer of the most recently waited launch
+    float last_ms = 0.f;
+    bool lost_warned = false;
+    uint64_t bytes = 0;
+};
+
+static inline v16 *plane(const kng_engine *h, int k) { return h->planes + (size_t)k * h->n; }
+
+extern "C" {
+
+const char *kng_last_error(void) { return g_err.c_str(); }
+const char *kng_version(void) { return "kangaroo_hip 0.1 (gfx950)"; }
+
+int kng_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int kng_device_info(int dev, char *name, size_t name_cap, int *cu_count, uint64_t *mem_bytes, char *arch,
+                    size_t arch_cap) {
+    if (dev < 0 || dev >= kng_device_count()) return fail(KNG_E_NODEVICE, "invalid device %d", dev);
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, dev));
+    if (name && name_cap) snprintf(name, name_cap, "%s", p.name);
+    if (arch && arch_cap) snprintf(arch, arch_cap, "%s", p.gcnArchName);
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (mem_bytes) *mem_bytes = (uint64_t)p.totalGlobalMem;
+    return KNG_OK;
+}
+
+int kng_default_grid(int dev, int *x, int *y) {
+    if (!x || !y) return fail(KNG_E_ARG, "null grid pointer");
+    if (*x <= 0 || *y <= 0) {
+        int cu = 0;
+        int rc = kng_device_info(dev, nullptr, 0, &cu, nullptr, nullptr, 0);
+        if (rc) return rc;
+        if (*x <= 0) *x = 2 * cu; // GPUEngine.cu:301
+        if (*y <= 0) *y = 128;    // GPUEngine.cu:302-303 (no per-SM core count for this arch)
+    }
+    return KNG_OK;
+}
+
+static void choose_geometry(kng_engine *h) {
+    // lanes L = n / group.  Default group: as large as possible (cheapest inversion share)
+    // while every SIMD of the chip still gets at least one wave.
+    if (h->group == 0) {
+        const uint64_t want_lanes = (uint64_t)h->cu_count * 4 * 64;
+        uint32_t g = KNG_GRP_SIZE;
+        while (g > 16 && h->n / g < want_lanes) g >>= 1;
+        h->group = g;
+    }
+    while (h->group > 1 && (h->n % h->group)) h->group >>= 1;
+    h->lanes = (uint32_t)(h->n / h->group);
+}
+
+int kng_create(int dev, int grid_x, int grid_y, uint32_t max_found, kng_engine **out) {
+    if (!out) return fail(KNG_E_ARG, "null out");
+    *out = nullptr;
+    if (grid_x <= 0 || grid_y <= 0 || max_found == 0) return fail(KNG_E_ARG, "bad grid %dx%d / max_found %u", grid_x, grid_y, max_found);
+    const int ndev = kng_device_count();
+    if (ndev == 0) return fail(KNG_E_NODEVICE, "no HIP device available (this engine has no CPU fallback)");
+    if (dev < 0 || dev >= ndev) return fail(KNG_E_NODEVICE, "invalid device %d (have %d)", dev, ndev);
+    HIP_TRY(hipSetDevice(dev));
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, dev));
+
+    kng_engine *h = new kng_engine();
+    h->dev = dev;
+    h->grid_x = grid_x;
+    h->grid_y = grid_y;
+    h->n = (uint64_t)grid_x * (uint64_t)grid_y * KNG_GRP_SIZE;
+    h->max_found = max_found;
+    h->cu_count = p.multiProcessorCount;
+    choose_geometry(h);
+
+    auto bail = [&](int code) {
+        kng_destroy(h);
+        return code;
+    };
+    hipError_t e;
+    const size_t plane_bytes = (size_t)h->n * sizeof(v16);
+    if ((e = hipMalloc((void **)&h->planes, 7 * plane_bytes)) != hipSuccess)
+        return bail(fail(KNG_E_ALLOC, "herd state (%zu bytes): %s", 7 * plane_bytes, hipGetErrorString(e)));
+    if ((e = hipMalloc((void **)&h->jtab, JT_WORDS * 8)) != hipSuccess) return bail(fail(KNG_E_ALLOC, "jump table: %s", hipGetErrorString(e)));
+    for (int s = 0; s < 2; s++) {
+        if ((e = hipMalloc((void **)&h->dp_count[s], 64)) != hipSuccess) return bail(fail(KNG_E_ALLOC, "dp counter: %s", hipGetErrorString(e)));
+        if ((e = hipMalloc((void **)&h->dp_items[s], (size_t)max_found * sizeof(DpRecord))) != hipSuccess)
+            return bail(fail(KNG_E_ALLOC, "dp items: %s", hipGetErrorString(e)));
+        // zero at allocation: the reference reads an uninitialised counter on its first Launch
+        if ((e = hipMemset(h->dp_count[s], 0, 64)) != hipSuccess) return bail(fail(KNG_E_HIP, "memset: %s", hipGetErrorString(e)));
+        if ((e = hipHostMalloc((void **)&h->h_count[s], 64, hipHostMallocDefault)) != hipSuccess)
+            return bail(fail(KNG_E_ALLOC, "pinned counter: %s", hipGetErrorString(e)));
+        *h->h_count[s] = 0;
+        if (hipEventCreate(&h->ev_start[s]) != hipSuccess || hipEventCreate(&h->ev_stop[s]) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_done[s], hipEventBlockingSync) != hipSuccess)
+            return bail(fail(KNG_E_HIP, "event creation failed"));
+    }
+    if ((e = hipHostMalloc((void **)&h->h_items, (size_t)max_found * sizeof(DpRecord), hipHostMallocDefault)) != hipSuccess)
+        return bail(fail(KNG_E_ALLOC, "pinned dp items: %s", hipGetErrorString(e)));
+    h->stage_kang = h->n < (1u << 16) ? (size_t)h->n : (size_t)(1u << 16);
+    if ((e = hipHostMalloc((void **)&h->h_stage, 5 * h->stage_kang * sizeof(v16), hipHostMallocDefault)) != hipSuccess)
+        return bail(fail(KNG_E_ALLOC, "pinned staging: %s", hipGetErrorString(e)));
+    if (hipStreamCreateWithFlags(&h->walk, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking) != hipSuccess)
+        return bail(fail(KNG_E_HIP, "stream creation failed"));
+    h->bytes = 7 * plane_bytes + JT_WORDS * 8 + 2 * (64 + (uint64_t)max_found * sizeof(DpRecord));
+    *out = h;
+    return KNG_OK;
+}
+
+void kng_destroy(kng_engine *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->dev);
+    if (h->walk) (void)hipStreamSynchronize(h->walk);
+    if (h->copy) (void)hipStreamSynchronize(h->copy);
+    if (h->planes) (void)hipFree(h->planes);
+    if (h->jtab) (void)hipFree(h->jtab);
+    for (int s = 0; s < 2; s++) {
+        if (h->dp_count[s]) (void)hipFree(h->dp_count[s]);
+        if (h->dp_items[s]) (void)hipFree(h->dp_items[s]);
+        if (h->h_count[s]) (void)hipHostFree(h->h_count[s]);
+        if (h->ev_start[s]) (void)hipEventDestroy(h->ev_start[s]);
+        if (h->ev_stop[s]) (void)hipEventDestroy(h->ev_stop[s]);
+        if (h->ev_done[s]) (void)hipEventDestroy(h->ev_done[s]);
+    }
+    if (h->h_items) (void)hipHostFree(h->h_items);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->walk) (void)hipStreamDestroy(h->walk);
+    if (h->copy) (void)hipStreamDestroy(h->copy);
+    delete h;
+}
+
+uint64_t kng_nb_kangaroos(const kng_engine *h) { return h ? h->n : 0; }
+uint64_t kng_memory_bytes(const kng_engine *h) { return h ? h->bytes : 0; }
+
+int kng_set_option(kng_engine *h, const char *key, int64_t value) {
+    if (!h || !key) return fail(KNG_E_ARG, "null argument");
+    if (h->outstanding) return fail(KNG_E_STATE, "cannot change options while a launch is outstanding");
+    std::string k(key);
+    if (k == "group") {
+        if (value < 1 || (value & (value - 1)) || (h->n % (uint64_t)value)) return fail(KNG_E_ARG, "group must be a power of two dividing the herd");
+        h->group = (uint32_t)value;
+        h->lanes = (uint32_t)(h->n / h->group);
+    } else if (k == "block") {
+        if (value < 64 || value > 256 || (value % 64)) return fail(KNG_E_ARG, "block must be 64,128,192 or 256");
+        h->block = (uint32_t)value;
+    } else if (k == "steps") {
+        if (value < 1 || value > 1 << 20) return fail(KNG_E_ARG, "steps out of range");
+        h->nsteps = (uint32_t)value;
+    } else {
+        return fail(KNG_E_ARG, "unknown option '%s'", key);
+    }
+    return KNG_OK;
+}
+
+int kng_get_option(const kng_engine *h, const char *key, int64_t *value) {
+    if (!h || !key || !value) return fail(KNG_E_ARG, "null argument");
+    std::string k(key);
+    if (k == "group") *value = h->group;
+    else if (k == "block") *value = h->block;
+    else if (k == "steps") *value = h->nsteps;
+    else if (k == "lanes") *value = h->lanes;
+    else if (k == "cu_count") *value = h->cu_count;
+    else if (k == "waves_per_cu") *value = h->cu_count ? (int64_t)((h->lanes / 64 + h->cu_count - 1) / h->cu_count) : 0;
+    else return fail(KNG_E_ARG, "unknown option '%s'", key);
+    return KNG_OK;
+}
+
+int kng_set_params(kng_engine *h, uint64_t dp_mask, const uint64_t *jd, const uint64_t *jx, const uint64_t *jy) {
+    if (!h || !jd || !jx || !jy) return fail(KNG_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->dev));
+    // limb-major table: word (plane p, entry j) at p*32 + j
+    uint64_t tab[JT_WORDS];
+    for (int j = 0; j < KNG_NB_JUMP; j++) {
+        for (int k = 0; k < 4; k++) {
+            tab[JT_JX + k * 32 + j] = jx[4 * j + k];
+            tab[JT_JY + k * 32 + j] = jy[4 * j + k];
+        }
+        tab[JT_JD + j] = jd[2 * j];
+        tab[JT_JD + 32 + j] = jd[2 * j + 1];
+    }
+    // stream-ordered after any in-flight launch
+    HIP_TRY(hipMemcpyAsync(h->jtab, tab, sizeof tab, hipMemcpyHostToDevice, h->walk));
+    HIP_TRY(hipStreamSynchronize(h->walk));
+    h->dp_mask = dp_mask;
+    h->have_params = true;
+    return KNG_OK;
+}
+
+int kng_set_kangaroos(kng_engine *h, const uint64_t *x, size_t xs, const uint64_t *y, size_t ys, const uint64_t *d,
+                      size_t ds, uint64_t n) {
+    if (!h || !x || !y || !d) return fail(KNG_E_ARG, "null argument");
+    if (n != h->n) return fail(KNG_E_ARG, "expected %llu kangaroos, got %llu", (unsigned long long)h->n, (unsigned long long)n);
+    if (xs < 4 || ys < 4 || ds < 2) return fail(KNG_E_ARG, "bad stride");
+    HIP_TRY(hipSetDevice(h->dev));
+    const size_t C = h->stage_kang;
+    for (uint64_t c0 = 0; c0 < n; c0 += C) {
+        const size_t m = (size_t)((n - c0 < C) ? (n - c0) : C);
+        v16 *st = h->h_stage;
+        for (size_t i = 0; i < m; i++) {
+            const uint64_t *px = x + (c0 + i) * xs, *py = y + (c0 + i) * ys, *pd = d + (c0 + i) * ds;
+            st[0 * C + i] = make_ulonglong2(px[0], px[1]);
+            st[1 * C + i] = make_ulonglong2(px[2], px[3]);
+            st[2 * C + i] = make_ulonglong2(py[0], py[1]);
+            st[3 * C + i] = make_ulonglong2(py[2], py[3]);
+            st[4 * C + i] = make_ulonglong2(pd[0], pd[1]);
+        }
+        for (int k = 0; k < 5; k++)
+            HIP_TRY(hipMemcpyAsync(plane(h, k) + c0, st + (size_t)k * C, m * sizeof(v16), hipMemcpyHostToDevice, h->walk));
+        HIP_TRY(hipStreamSynchronize(h->walk)); // staging buffer is reused
+    }
+    h->have_herd = true;
+    return KNG_OK;
+}
+
+int kng_get_kangaroos(kng_engine *h, uint64_t *x, size_t xs, uint64_t *y, size_t ys, uint64_t *d, size_t ds, uint64_t n) {
+    if (!h || !x || !y || !d) return fail(KNG_E_ARG, "null argument");
+    if (n != h->n) return fail(KNG_E_ARG, "expected %llu kangaroos, got %llu", (unsigned long long)h->n, (unsigned long long)n);
+    if (xs < 4 || ys < 4 || ds < 2) return fail(KNG_E_ARG, "bad stride");
+    if (!h->have_herd) return fail(KNG_E_STATE, "no herd loaded");
+    HIP_TRY(hipSetDevice(h->dev));
+    const size_t C = h->stage_kang;
+    for (uint64_t c0 = 0; c0 < n; c0 += C) {
+        const size_t m = (size_t)((n - c0 < C) ? (n - c0) : C);
+        v16 *st = h->h_stage;
+        // stream-ordered behind an in-flight launch: returns the state that launch leaves
+        for (int k = 0; k < 5; k++)
+            HIP_TRY(hipMemcpyAsync(st + (size_t)k * C, plane(h, k) + c0, m * sizeof(v16), hipMemcpyDeviceToHost, h->walk));
+        HIP_TRY(hipStreamSynchronize(h->walk));
+        for (size_t i = 0; i < m; i++) {
+            uint64_t *px = x + (c0 + i) * xs, *py = y + (c0 + i) * ys, *pd = d + (c0 + i) * ds;
+            px[0] = st[0 * C + i].x; px[1] = st[0 * C + i].y; px[2] = st[1 * C + i].x; px[3] = st[1 * C + i].y;
+            py[0] = st[2 * C + i].x; py[1] = st[2 * C + i].y; py[2] = st[3 * C + i].x; py[3] = st[3 * C + i].y;
+            pd[0] = st[4 * C + i].x; pd[1] = st[4 * C + i].y;
+        }
+    }
+    return KNG_OK;
+}
+
+int kng_set_kangaroo(kng_engine *h, uint64_t kidx, const uint64_t x[4], const uint64_t y[4], const uint64_t d[2]) {
+    if (!h || !x || !y || !d) return fail(KNG_E_ARG, "null argument");
+    if (kidx >= h->n) return fail(KNG_E_ARG, "kIdx %llu out of range", (unsigned long long)kidx);
+    HIP_TRY(hipSetDevice(h->dev));
+    fe fx{{x[0], x[1], x[2], x[3]}}, fy{{y[0], y[1], y[2], y[3]}};
+    hipLaunchKernelGGL(kng_patch_kernel, dim3(1), dim3(1), 0, h->walk, plane(h, 0), plane(h, 1), plane(h, 2), plane(h, 3),
+                       plane(h, 4), kidx, fx, fy, make_ulonglong2(d[0], d[1]));
+    HIP_TRY(hipGetLastError());
+    return KNG_OK;
+}
+
+int kng_launch(kng_engine *h) {
+    if (!h) return fail(KNG_E_ARG, "null engine");
+    if (!h->have_params) return fail(KNG_E_STATE, "kng_set_params has not been called");
+    if (!h->have_herd) return fail(KNG_E_STATE, "kng_set_kangaroos has not been called");
+    if (h->outstanding) return fail(KNG_E_STATE, "a launch is already outstanding; call kng_wait first");
+    HIP_TRY(hipSetDevice(h->dev));
+    const int s = h->slot_next;
+    WalkArgs a;
+    a.x01 = plane(h, 0); a.x23 = plane(h, 1); a.y01 = plane(h, 2); a.y23 = plane(h, 3);
+    a.d = plane(h, 4); a.s01 = plane(h, 5); a.s23 = plane(h, 6);
+    a.jtab = h->jtab;
+    a.dp_mask = h->dp_mask;
+    a.dp_count = h->dp_count[s];
+    a.dp_items = h->dp_items[s];
+    a.max_found = h->max_found;
+    a.lanes = h->lanes;
+    a.group = h->group;
+    a.nsteps = h->nsteps;
+    HIP_TRY(hipMemsetAsync(h->dp_count[s], 0, 4, h->walk)); // GPUEngine.cu:543
+    HIP_TRY(hipEventRecord(h->ev_start[s], h->walk));
+    const uint32_t blocks = (h->lanes + h->block - 1) / h->block;
+    hipLaunchKernelGGL(kng_walk_kernel, dim3(blocks), dim3(h->block), 0, h->walk, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev_stop[s], h->walk));
+    HIP_TRY(hipMemcpyAsync(h->h_count[s], h->dp_count[s], 4, hipMemcpyDeviceToHost, h->walk));
+    HIP_TRY(hipEventRecord(h->ev_done[s], h->walk));
+    h->outstanding = true;
+    return KNG_OK;
+}
+
+int kng_wait(kng_engine *h, int spin) {
+    if (!h) return fail(KNG_E_ARG, "null engine");
+    if (!h->outstanding) return fail(KNG_E_STATE, "no launch outstanding");
+    HIP_TRY(hipSetDevice(h->dev));
+    const int s = h->slot_next;
+    if (spin) {
+        hipError_t e;
+        while ((e = hipEventQuery(h->ev_done[s])) == hipErrorNotReady) {
+        }
+        if (e != hipSuccess) return fail(KNG_E_HIP, "walk kernel: %s", hipGetErrorString(e));
+    } else {
+        HIP_TRY(hipEventSynchronize(h->ev_done[s])); // blocking-sync event: the host thread sleeps
+    }
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev_start[s], h->ev_stop[s]));
+    h->last_ms = ms;
+    h->outstanding = false;
+    h->slot_ready = s;
+    h->slot_next = s ^ 1;
+    return KNG_OK;
+}
+
+int kng_drain(kng_engine *h, kng_item *items, uint32_t cap, uint32_t *n_items, uint32_t *n_lost) {
+    if (!h || !n_items) return fail(KNG_E_ARG, "null argument");
+    *n_items = 0;
+    if (n_lost) *n_lost = 0;
+    if (h->slot_ready < 0) return KNG_OK; // nothing waited yet (first Launch of the reference protocol)
+    HIP_TRY(hipSetDevice(h->dev));
+    const int s = h->slot_ready;
+    uint32_t found = *h->h_count[s];
+    uint32_t lost = 0;
+    if (found > h->max_found) { // GPUEngine.cu:641-648
+        lost = found - h->max_found;
+        found = h->max_found;
+    }
+    if (found > cap) {
+        lost += found - cap;
+        found = cap;
+    }
+    if (found && !items) return fail(KNG_E_ARG, "null items with %u points pending", found);
+    if (found) {
+        HIP_TRY(hipMemcpyAsync(h->h_items, h->dp_items[s], (size_t)found * sizeof(DpRecord), hipMemcpyDeviceToHost, h->copy));
+        HIP_TRY(hipStreamSynchronize(h->copy));
+        for (uint32_t i = 0; i < found; i++) {
+            memcpy(items[i].x, h->h_items[i].x, 32);
+            items[i].d[0] = h->h_items[i].d[0];
+            items[i].d[1] = h->h_items[i].d[1];
+            items[i].kidx = h->h_items[i].kidx;
+        }
+    }
+    *n_items = found;
+    if (n_lost) *n_lost = lost;
+    h->slot_ready = -1; // drained
+    return KNG_OK;
+}
+
+int kng_last_kernel_ms(const kng_engine *h, float *ms) {
+    if (!h || !ms) return fail(KNG_E_ARG, "null argument");
+    *ms = h->last_ms;
+    return KNG_OK;
+}
+
+int kng_test_fieldop(int dev, int op, const uint64_t *a, const uint64_t *b, uint64_t *r, uint64_t n) {
+    if (!a || !b || !r) return fail(KNG_E_ARG, "null argument");
+    if (op < KNG_OP_MODMUL || op > KNG_OP_MODINV) return fail(KNG_E_ARG, "unknown op %d", op);
+    if (n == 0) return KNG_OK;
+    if (dev < 0 || dev >= kng_device_count()) return fail(KNG_E_NODEVICE, "invalid device %d (no CPU fallback)", dev);
+    HIP_TRY(hipSetDevice(dev));
+    uint64_t *da = nullptr, *db = nullptr, *dr = nullptr;
+    const size_t bytes = (size_t)n * 32;
+    HIP_TRY(hipMalloc((void **)&da, bytes));
+    HIP_TRY(hipMalloc((void **)&db, bytes));
+    HIP_TRY(hipMalloc((void **)&dr, bytes));
+    HIP_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kng_fieldop_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, op, da, db, dr, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(r, dr, bytes, hipMemcpyDeviceToHost));
+    (void)hipFree(da);
+    (void)hipFree(db);
+    (void)hipFree(dr);
+    return KNG_OK;
+}
+
+} // extern "C"

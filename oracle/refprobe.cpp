@@ -308,14 +308,14 @@ int main(int argc, char **argv) {
   /* Check.cpp:472-476 constants (64-bit range), small herd so the fixture stays small */
   emit_walk(secp, "walk_check64", "5B3F38AF935A3640D158E871CE6E9666DB862636383386EE0000000000000000",
             "5B3F38AF935A3640D158E871CE6E9666DB862636383386EEFFFFFFFFFFFFFFFF",
-            "5B3F38AF935A3640D158E871CE6E9666DB862636383386EE0000000000123000", 96, 4, NB_RUN, seed + 2, false);
+            "5B3F38AF935A3640D158E871CE6E9666DB862636383386EE0000000000123000", 256, 4, NB_RUN, seed + 2, false);
   /* 80-bit range */
   emit_walk(secp, "walk_80", "B60E83280258A40F9CDF1649744D730D6E939DE92A2B00000000000000000000",
             "B60E83280258A40F9CDF1649744D730D6E939DE92A2BFFFFFFFFFFFFFFFFFFFF",
-            "B60E83280258A40F9CDF1649744D730D6E939DE92A2B00000C0FFEE123456789", 64, 3, NB_RUN, seed + 3, false);
+            "B60E83280258A40F9CDF1649744D730D6E939DE92A2B00000C0FFEE123456789", 128, 3, NB_RUN, seed + 3, false);
   /* 125-bit (max) range: wild distances wrap mod n */
   emit_walk(secp, "walk_125", "0", "1FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF",
-            "0000000000000000000000000000000012345678FEDCBA9876543210DEADBEEF", 64, 2,
+            "0000000000000000000000000000000012345678FEDCBA9876543210DEADBEEF", 128, 2,
             2 * NB_RUN, seed + 4, true);
   fprintf(out, "}\n");
   fclose(out);

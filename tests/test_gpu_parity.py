@@ -1,0 +1,240 @@
+"""GPU parity tests proper: the HIP engine, called through the C ABI, against the CPU oracle
+and against vectors produced by the reference's own objects.  Bit-exact everywhere (integer path).
+
+These mirror `kangaroo -gpu -check` (Check.cpp:467-621): SetParams / SetWildOffset / SetKangaroos,
+single-kangaroo overwrite, Launch; GetKangaroos; Launch, then compare every (x, y, d) and the DP
+list -- but with an exact DP multiset comparison (the reference never checks for extra GPU DPs,
+SURVEY App. D.3).
+"""
+import numpy as np
+import pytest
+
+from helpers import (M128, N_ORDER, array_to_ints, device_distances, dp_multiset, ints_to_array, walk_fixture)
+
+pytestmark = pytest.mark.gpu
+
+H = lambda s: int(s, 16)  # noqa: E731
+
+
+@pytest.fixture(scope="module")
+def kng():
+    import kangaroo_amd
+
+    kangaroo_amd.load_library()  # raises if the HIP library was not built: no fallback
+    assert kangaroo_amd.device_count() >= 1, "no HIP device visible"
+    info = kangaroo_amd.device_info(0)
+    assert "gfx950" in info["arch"], info
+    return kangaroo_amd
+
+
+# ------------------------------------------------------------------ primitives
+def _pairs(vecs):
+    a = ints_to_array([H(v[0]) for v in vecs])
+    b = ints_to_array([H(v[1]) for v in vecs])
+    return a, b
+
+
+def test_modmul_golden(kng, golden):
+    a, b = _pairs(golden["modmul"])
+    r = kng.test_fieldop("modmul", a, b)
+    assert array_to_ints(r) == [H(v[2]) for v in golden["modmul"]]
+
+
+def test_modsqr_golden(kng, golden):
+    a = ints_to_array([H(v[0]) for v in golden["modsqr"]])
+    r = kng.test_fieldop("modsqr", a)
+    assert array_to_ints(r) == [H(v[1]) for v in golden["modsqr"]]
+
+
+def test_modsub_golden(kng, golden):
+    a, b = _pairs(golden["modsub"])
+    r = kng.test_fieldop("modsub", a, b)
+    assert array_to_ints(r) == [H(v[2]) & ((1 << 256) - 1) for v in golden["modsub"]]
+
+
+def test_modinv_golden(kng, golden):
+    a = ints_to_array([H(v[0]) for v in golden["modinv"]])
+    r = kng.test_fieldop("modinv", a)
+    assert array_to_ints(r) == [H(v[1]) for v in golden["modinv"]]
+
+
+@pytest.mark.parametrize("op", ["modmul", "modsqr", "modsub", "modinv"])
+def test_primitives_random_vs_oracle(kng, orc, op):
+    rng = np.random.default_rng(1234)
+    n = 20000 if op != "modinv" else 4096
+    a = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    b = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    # sprinkle values just below 2^256 (non-canonical operands, carry corners of the fold)
+    a[::97, 1:] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    b[::89, 1:] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    got = kng.test_fieldop(op, a, b)
+    want = np.zeros_like(a)
+    fn = getattr(orc.lib, "orc_" + op)
+    for i in range(n):
+        if op in ("modmul", "modsub"):
+            fn(want[i], a[i], b[i])
+        else:
+            fn(want[i], a[i])
+    assert np.array_equal(got, want)
+
+
+def test_fieldop_empty(kng):
+    e = np.zeros((0, 4), dtype=np.uint64)
+    assert kng.test_fieldop("modmul", e, e).shape == (0, 4)
+
+
+# ------------------------------------------------------------------ the walk, reference vectors
+def _run_check_protocol(kng, w, jd, jx, jy, grid, launches, **opts):
+    """Check.cpp:492-528 protocol generalised to `launches` kernels."""
+    n = len(w["start"])
+    eng = kng.GPUEngine(grid[0], grid[1], 0, 65536, **opts)
+    assert eng.nbKangaroo == n
+    eng.SetParams(w["dp_mask"], jd, jx, jy)
+    eng.SetWildOffset(w["wild_offset"])
+    eng.SetKangaroos(ints_to_array([s[0] for s in w["start"]]), ints_to_array([s[1] for s in w["start"]]),
+                     ints_to_array([s[2] for s in w["start"]]))
+    dps = []
+    first = eng.Launch()
+    assert len(first) == 0
+    for _ in range(launches - 1):
+        dps.append(eng.Launch())
+    px, py, pd = eng.GetKangaroos()  # blocks until the in-flight kernel is done
+    eng.wait()
+    dps.append(eng.drain())
+    eng.close()
+    allp = [(int(r["kidx"]), array_to_ints([r["x"]])[0], array_to_ints([r["d"]])[0]) for part in dps for r in part]
+    return list(zip(array_to_ints(px), array_to_ints(py), array_to_ints(pd))), allp
+
+
+@pytest.mark.parametrize("name,grid,launches", [("walk_check64", (2, 1), 1), ("walk_80", (1, 1), 1),
+                                                ("walk_125", (1, 1), 2)])
+@pytest.mark.parametrize("group", [1, 4, 128])
+def test_walk_matches_reference_vectors(kng, orc, golden, name, grid, launches, group):
+    w = walk_fixture(golden[name])
+    assert w["nsteps"] == 64 * launches
+    jd, jx, jy, _ = orc.jump_table(w["range_power"])
+    end, dps = _run_check_protocol(kng, w, jd, jx, jy, grid, launches, group=group)
+    assert end == w["end"]
+    assert dp_multiset(dps) == dp_multiset(w["dps"])
+
+
+# ------------------------------------------------------------------ the walk, seeded herds vs the oracle
+def _seeded_herd(orc, n, range_power, seed):
+    rng = np.random.default_rng(seed)
+    key = int(rng.integers(1, 1 << 62)) | (1 << (range_power - 1))
+    _, kx, ky = orc.pubkey(key)
+    width = (1 << range_power) - 1
+    wild_offset = width >> 1
+    true_d = []
+    for i in range(n):
+        d = int.from_bytes(rng.bytes(16), "little") & width
+        if i & 1:
+            d = (d - wild_offset) % N_ORDER
+        true_d.append(d)
+    d4 = ints_to_array(true_d)
+    x, y = orc.create_herd(d4, 0, kx, ky)
+    return x, y, true_d, wild_offset
+
+
+@pytest.mark.parametrize("grid,group,block,launches,dp", [
+    ((2, 2), 1, 64, 1, 5),
+    ((2, 2), 2, 64, 2, 5),
+    ((3, 5), 8, 128, 2, 4),      # lanes not a multiple of the block: ragged last workgroup
+    ((4, 4), 32, 256, 3, 6),
+    ((2, 4), 128, 64, 2, 0),     # dp=0: every jump is a DP -> 64*n points, exercises max_found clamp
+    ((8, 4), 64, 64, 1, 7),
+])
+def test_walk_vs_oracle(kng, orc, grid, group, block, launches, dp):
+    n = grid[0] * grid[1] * 128
+    rp = 72
+    x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=grid[0] * 100 + group)
+    jd, jx, jy, _ = orc.jump_table(rp)
+    mask = orc.dp_mask(dp)
+    max_found = 1 << 16
+    eng = kng.GPUEngine(grid[0], grid[1], 0, max_found, group=group, block=block)
+    eng.SetParams(mask, jd, jx, jy)
+    eng.SetWildOffset(wild_offset)
+    eng.SetKangaroos(x, y, ints_to_array(true_d))
+
+    ox, oy = x.copy(), y.copy()
+    od = ints_to_array(device_distances(true_d, wild_offset), 2)
+    for launch in range(launches):
+        eng.callKernel()
+        eng.wait()
+        got = eng.drain(raw=True)
+        want, total = orc.walk(ox, oy, od, 64, jd, jx, jy, mask, dp_cap=1 << 22)
+        if total <= max_found:
+            assert eng.lastLost == 0
+            assert dp_multiset((r["kidx"], array_to_ints([r["x"]])[0], array_to_ints([r["d"]])[0]) for r in got) == \
+                dp_multiset((r["kidx"], array_to_ints([r["x"]])[0], array_to_ints([r["d"]])[0]) for r in want)
+        else:
+            # GPUEngine.cu:641-648: surplus points are dropped and counted
+            assert len(got) == max_found and eng.lastLost == total - max_found
+            wantset = set(dp_multiset((r["kidx"], array_to_ints([r["x"]])[0], array_to_ints([r["d"]])[0]) for r in want))
+            assert all((int(r["kidx"]), array_to_ints([r["x"]])[0], array_to_ints([r["d"]])[0]) in wantset for r in got[::37])
+        gx, gy, gd = eng.GetKangaroos(raw=True)
+        assert np.array_equal(gx, ox) and np.array_equal(gy, oy) and np.array_equal(gd, od), f"launch {launch}"
+    eng.close()
+
+
+def test_set_get_roundtrip_and_single_overwrite(kng, orc):
+    """SetKangaroos/GetKangaroos are exact inverses incl. the wild offset (GPUEngine.cu:381-480);
+    SetKangaroo (GPUEngine.cu:483-538) lands after an in-flight launch."""
+    grid = (2, 3)
+    n = grid[0] * grid[1] * 128
+    rp = 125
+    x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=7)
+    jd, jx, jy, _ = orc.jump_table(rp)
+    eng = kng.GPUEngine(grid[0], grid[1], 0, 4096, group=16)
+    eng.SetParams(orc.dp_mask(10), jd, jx, jy)
+    eng.SetWildOffset(wild_offset)
+    eng.SetKangaroos(x, y, ints_to_array(true_d))
+    gx, gy, gd = eng.GetKangaroos()
+    assert np.array_equal(gx, x) and np.array_equal(gy, y) and array_to_ints(gd) == true_d
+
+    # overwrite kangaroo r (odd -> wild) while a launch is in flight: takes effect after it
+    r = 777
+    assert r & 1
+    nd = (true_d[r] + 12345) % N_ORDER
+    _, nx, ny = orc.pubkey(99)
+    eng.callKernel()
+    eng.SetKangaroo(r, nx, ny, nd)
+    eng.wait()
+    gx, gy, gd = eng.GetKangaroos()
+    assert array_to_ints(gx[r:r + 1])[0] == nx and array_to_ints(gy[r:r + 1])[0] == ny
+    assert array_to_ints(gd[r:r + 1])[0] == nd
+    # everyone else did exactly 64 jumps
+    ox, oy = x.copy(), y.copy()
+    od = ints_to_array(device_distances(true_d, wild_offset), 2)
+    orc.walk(ox, oy, od, 64, jd, jx, jy, 0, dp_cap=0)
+    keep = np.arange(n) != r
+    assert np.array_equal(gx[keep], ox[keep]) and np.array_equal(gy[keep], oy[keep])
+    eng.close()
+
+
+def test_call_sequence_errors(kng, orc):
+    eng = kng.GPUEngine(1, 1, 0, 16)
+    with pytest.raises(kng.EngineError):
+        eng.callKernel()  # no params / herd yet
+    jd, jx, jy, _ = orc.jump_table(64)
+    eng.SetParams(0, jd, jx, jy)
+    with pytest.raises(kng.EngineError):
+        eng.callKernel()  # no herd
+    with pytest.raises(kng.EngineError):
+        eng.SetKangaroos(np.zeros((5, 4), np.uint64), np.zeros((5, 4), np.uint64), np.zeros((5, 2), np.uint64))
+    with pytest.raises(kng.EngineError):
+        eng.set_option("group", 3)
+    eng.close()
+    with pytest.raises(kng.EngineError):
+        kng.GPUEngine(1, 1, 99, 16)  # bad device id
+
+
+def test_default_grid_and_banner(kng):
+    x, y = kng.default_grid(0)
+    info = kng.device_info(0)
+    assert x == 2 * info["cu_count"] and y == 128  # GPUEngine.cu:301-303
+    assert kng.default_grid(0, 7, 9) == (7, 9)
+    eng = kng.GPUEngine(1, 1, 0, 16)
+    assert eng.deviceName.startswith("GPU #0 ") and "Grid(1x1)" in eng.deviceName
+    assert eng.GetGroupSize() == 128 and eng.GetNbThread() == 1 and eng.GetMemory() > 0
+    eng.close()
