@@ -1,0 +1,272 @@
+#!/usr/bin/env python3
+"""bench.py -- kangaroo jumps/s of the MI355X jump engine on BASELINE.json's throughput config.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2] / SURVEY.md 8d config 3): 80-bit range, one synthetic key with a
+known answer, reference-default grid 2*CU x 128 threads x 128 kangaroos = 2^23 kangaroos per GPU,
+auto DP (Kangaroo.cpp:980-988 -> 14 at one GPU), reference jump table (seed 0x600DCAFE).
+One "step" = one engine launch = NB_RUN = 64 jumps of every kangaroo (Kangaroo.cpp:574-575), with
+the previous launch's distinguished points drained to the host while the next one runs.
+Herds are independent per GPU (no collective on the data path; Kangaroo.cpp:1041-1047) -> weak scaling.
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the engine's own
+stream; `cpu_baseline` (N=1 only) times the reference's SolveKeyCPU binary (oracle/_ref/kangaroo_cpu,
+built from the reference sources) on this host, or the oracle port when that binary is absent.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+RANGE_POWER = 80
+RANGE_START = int("B60E83280258A40F9CDF1649744D730D6E939DE92A2B" + "0" * 20, 16)
+KEY = RANGE_START + 0xC0FFEE123456789ABCD  # 80-bit offset, answer known
+ALG_BYTES_PER_JUMP = 160  # read + write of x(32) y(32) d(16): SURVEY.md 8d
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def log(msg):
+    print(msg, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(seconds: float = 20.0) -> dict:
+    """Reference SolveKeyCPU path on this host's cores (bounded sample)."""
+    import kangaroo_amd.hostlib as hl
+
+    cores = os.cpu_count() or 1
+    ref = os.path.join(ROOT, "oracle", "_ref", "kangaroo_cpu")
+    _, kx, ky = hl.pubkey(KEY)
+    pub = ("02" if ky % 2 == 0 else "03") + f"{kx:064X}"
+    if os.path.exists(ref):
+        import pty
+        import select
+
+        with tempfile.TemporaryDirectory() as td:
+            cfg = os.path.join(td, "in80.txt")
+            with open(cfg, "w") as f:
+                f.write(f"{RANGE_START:064X}\n{RANGE_START + (1 << RANGE_POWER) - 1:064X}\n{pub}\n")
+            # the status line is printf("\r[%.2f MK/s]...") without fflush (Thread.cpp:306-314): use a pty
+            master, slave = pty.openpty()
+            proc = subprocess.Popen([ref, "-t", str(cores), cfg], stdout=slave, stderr=slave, close_fds=True)
+            os.close(slave)
+            buf = b""
+            t0 = time.time()
+            while time.time() - t0 < seconds:
+                r, _, _ = select.select([master], [], [], 0.5)
+                if r:
+                    try:
+                        chunk = os.read(master, 65536)
+                    except OSError:
+                        break
+                    if not chunk:
+                        break
+                    buf += chunk
+                if proc.poll() is not None:
+                    break
+            proc.kill()
+            proc.wait()
+            os.close(master)
+        rates = [float(m) for m in re.findall(rb"\[([0-9.]+) MK/s\]\[GPU", buf)]
+        steady = rates[3:] if len(rates) > 6 else rates  # 8-sample moving average: skip the ramp
+        if steady:
+            steady.sort()
+            return {"value": steady[len(steady) // 2], "unit": "MK/s", "cores": cores, "kind": "reference",
+                    "sample": f"reference kangaroo -t {cores} on the same 80-bit input for {seconds:.0f} s, median of "
+                              f"{len(steady)} status samples"}
+    # fallback: the oracle's batched walk (single thread)
+    import numpy as np
+
+    from oracle import load_oracle
+
+    orc = load_oracle()
+    n = 1024  # CPU_GRP_SIZE, Kangaroo.cpp:68
+    x, y, d, woff = hl.create_herd(n, RANGE_POWER, (kx, ky), seed=99, nthreads=1)
+    jd, jx, jy, _ = orc.jump_table(RANGE_POWER)
+    dd = hl.to_device_distances(d, woff)
+    steps = 0
+    t0 = time.time()
+    while time.time() - t0 < min(seconds, 10.0):
+        orc.walk(x, y, dd, 64, jd, jx, jy, hl.dp_mask(14), dp_cap=0)
+        steps += 64
+    el = time.time() - t0
+    return {"value": n * steps / el / 1e6, "unit": "MK/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/kng_oracle.c orc_walk, 1024 kangaroos x {steps} jumps, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", default="", help="gridX,gridY (default: reference defaults 2*CU,128)")
+    ap.add_argument("--group", type=int, default=0, help="kangaroos per lane (0 = engine default)")
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
+    n_gpus = max(world, 1)
+
+    # torch is plumbing here: rendezvous/barrier over RCCL and the cross-rank max of the timings
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+
+    import kangaroo_amd as k
+    import kangaroo_amd.hostlib as hl
+
+    k.load_library()  # raises when the HIP engine is missing: no fallback
+    if k.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: no HIP device {local_rank}")
+    dev = local_rank
+    info = k.device_info(dev)
+
+    if args.grid:
+        gx, gy = (int(v) for v in args.grid.split(","))
+    else:
+        gx, gy = k.default_grid(dev)  # 2*CU x 128 (GPUEngine.cu:299-303)
+    n = gx * gy * k.KNG_GRP_SIZE
+    total_rw = n * n_gpus
+    dp = hl.suggest_dp(RANGE_POWER, total_rw)
+    jd, jx, jy, javg = hl.jump_table(RANGE_POWER)
+    _, kx, ky = hl.pubkey(KEY)
+    # keyToSearch is shifted by the range start (Kangaroo.cpp:892-909): K - start*G
+    _, sx, sy = hl.pubkey(RANGE_START)
+    P = 2**256 - 0x1000003D1
+    _, ksx, ksy = hl.point_add((kx, ky), (sx, P - sy))
+
+    t0 = time.time()
+    x, y, d_true, woff = hl.create_herd(n, RANGE_POWER, (ksx, ksy), first_type=0, seed=0xBEEF + rank)
+    t_herd = time.time() - t0
+    opts = {}
+    if args.group:
+        opts["group"] = args.group
+    if args.block:
+        opts["block"] = args.block
+    eng = k.GPUEngine(gx, gy, dev, 65536 * 2, **opts)  # maxFound as Kangaroo.cpp:523
+    eng.SetParams(hl.dp_mask(dp), jd, jx, jy)
+    eng.SetWildOffset(woff)
+    t0 = time.time()
+    eng.SetKangaroos(x, y, hl.to_device_distances(d_true, woff))
+    t_up = time.time() - t0
+    del x, y, d_true
+    if rank == 0:
+        log(f"{eng.deviceName}: 2^{np.log2(n):.2f} kangaroos, dp {dp}, jump avg 2^{javg:.2f}, "
+            f"group {eng.get_option('group')} lanes {eng.get_option('lanes')} "
+            f"({eng.GetMemory() / 1048576.0:.1f} MB); herd built in {t_herd:.1f}s, uploaded in {t_up:.1f}s")
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warmup: W full steps
+    for _ in range(args.warmup):
+        eng.callKernel()
+        eng.wait()
+        eng.drain(raw=True)
+
+    kernel_ms = []
+    dps = 0
+    lost = 0
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.callKernel()
+        # drain the previous step's DPs while this launch runs (async drain, DP buffers are double-buffered)
+        if kernel_ms:
+            dps += len(eng.drain(raw=True))
+            lost += eng.lastLost
+        eng.wait()
+        kernel_ms.append(eng.last_kernel_ms())
+    dps += len(eng.drain(raw=True))
+    lost += eng.lastLost
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    jumps_per_step = n * k.KNG_NB_RUN
+    value = n_gpus * jumps_per_step * args.steps / elapsed / 1e6  # MK/s, whole job
+    kms = float(np.mean(kernel_ms))
+    achieved = jumps_per_step * ALG_BYTES_PER_JUMP / (kms * 1e-3) / 1e9  # GB/s, per GPU
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-measured HBM bytes per launch, if recorded
+    if os.path.exists(tfile):
+        try:
+            with open(tfile) as f:
+                tj = json.load(f)
+            if tj.get("kangaroos") == n and tj.get("group") == eng.get_option("group"):
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "kangaroo jumps/sec (MK/s)",
+        "value": round(value, 2),
+        "unit": "MK/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"80-bit range single key, auto DP {dp}, herd {gx}x{gy}x128 = 2^{np.log2(n):.0f} kangaroos/GPU, "
+                        f"{k.KNG_NB_RUN} jumps/launch",
+            "range_power": RANGE_POWER, "dp": dp, "grid": [gx, gy], "kangaroos_per_gpu": n,
+            "group": eng.get_option("group"), "lanes": eng.get_option("lanes"), "device": info["name"], "arch": info["arch"],
+            "parallelism": f"independent herds x{n_gpus}, no collective",
+            "dps_per_step": round(dps / args.steps, 1), "dps_lost": lost,
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "kernel": "kng_walk_kernel", "kernel_ms": round(kms, 3),
+            "alg_bytes_per_launch": jumps_per_step * ALG_BYTES_PER_JUMP,
+        },
+    }
+    eng.close()
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline()
+        except Exception as e:  # the baseline is reported, never required
+            out["cpu_baseline"] = {"value": None, "unit": "MK/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

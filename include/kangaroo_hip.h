@@ -94,6 +94,8 @@ int kng_set_kangaroo(kng_engine *h, uint64_t kidx, const uint64_t x[4], const ui
 /* start KNG_NB_RUN jumps for every kangaroo, asynchronously.  At most one launch may be
  * outstanding (not yet waited for). */
 int kng_launch(kng_engine *h);
+/* 1 when a launch has been started and not yet waited for, else 0 */
+int kng_outstanding(const kng_engine *h);
 /* block until the outstanding launch has finished.  spin != 0 busy-waits, otherwise the host
  * thread sleeps on the completion event (the reference polls with 1 ms sleeps, :621-629). */
 int kng_wait(kng_engine *h, int spin);
@@ -122,6 +124,10 @@ int kng_get_option(const kng_engine *h, const char *key, int64_t *value);
 #define KNG_OP_MODSUB 2 /* GPUMath.h:476-494  */
 #define KNG_OP_MODINV 3 /* GPUMath.h:700-803  */
 int kng_test_fieldop(int dev, int op, const uint64_t *a, const uint64_t *b, uint64_t *r, uint64_t n);
+
+/* ---- pinned host memory: AllocatePinnedMemory/FreePinnedMemory, GPUEngine.cu:311-327 ---------- */
+void *kng_alloc_pinned(size_t size); /* NULL on failure */
+void kng_free_pinned(void *p);
 
 const char *kng_last_error(void); /* thread-local text of the last failure */
 const char *kng_version(void);

@@ -550,6 +550,21 @@ int kng_launch(kng_engine *h) {
     return KNG_OK;
 }
 
+int kng_outstanding(const kng_engine *h) { return (h && h->outstanding) ? 1 : 0; }
+
+void *kng_alloc_pinned(size_t size) {
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, size, hipHostMallocPortable);
+    if (e != hipSuccess) {
+        fail(KNG_E_ALLOC, "hipHostMalloc(%zu): %s", size, hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+void kng_free_pinned(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int kng_wait(kng_engine *h, int spin) {
     if (!h) return fail(KNG_E_ARG, "null engine");
     if (!h->outstanding) return fail(KNG_E_STATE, "no launch outstanding");

@@ -1,0 +1,214 @@
+// GPUEngine.cpp -- `class GPUEngine` (reference boundary GPU/GPUEngine.h:40-64) implemented over
+// the C ABI of libkangaroo_hip.so.  Replaces the host half of GPU/GPUEngine.cu.
+//
+// Two build modes, one source:
+//   default                 : stand-alone, with our GPUEngine.h / Int.h
+//   -DKNG_REFERENCE_HEADER  : compiled against the REFERENCE's own GPU/GPUEngine.h and SECPK1/Int.h
+//                             (-I<reference root>); this object then replaces GPU/GPUEngine.o in the
+//                             reference's link line and the unmodified program runs on the MI355X.
+//                             The reference header's private fields are CUDA-era buffers we do not
+//                             need; the engine handle is parked in `inputKangaroo`.
+// Errors are loud: the reference printf()s and carries on with an unusable object
+// (GPUEngine.cu:144-253, callers never check `initialised`); we print and exit(1).
+#ifdef KNG_REFERENCE_HEADER
+#include "GPU/GPUEngine.h"
+#include "kangaroo_hip.h"
+#define ENGINE (*reinterpret_cast<kng_engine **>(&this->inputKangaroo))
+#else
+#include "GPUEngine.h"
+#define ENGINE (this->engine)
+#endif
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+static const size_t INT_STRIDE = sizeof(Int) / sizeof(uint64_t);
+
+static void die(const char *where) {
+  fprintf(stderr, "GPUEngine: %s: %s\n", where, kng_last_error());
+  exit(1);
+}
+#define KNG_MUST(call, where) do { if ((call) != KNG_OK) die(where); } while (0)
+
+GPUEngine::GPUEngine(int nbThreadGroup, int nbThreadPerGroup, int gpuId, uint32_t maxFound) {
+#ifdef KNG_REFERENCE_HEADER
+  inputKangaroo = NULL;
+  inputKangarooPinned = NULL;
+  outputItem = NULL;
+  outputItemPinned = NULL;
+  jumpPinned = NULL;
+  initialised = false;
+  dpMask = 0;
+#endif
+  this->nbThreadPerGroup = nbThreadPerGroup;
+  this->nbThread = nbThreadGroup * nbThreadPerGroup;
+  this->maxFound = maxFound;
+  this->lostWarning = false;
+  wildOffset.SetInt32(0);
+  ENGINE = NULL;
+  kng_engine *h = NULL;
+  KNG_MUST(kng_create(gpuId, nbThreadGroup, nbThreadPerGroup, maxFound, &h), "kng_create");
+  ENGINE = h;
+  char name[256] = "", arch[64] = "";
+  int cu = 0;
+  kng_device_info(gpuId, name, sizeof name, &cu, NULL, arch, sizeof arch);
+  char tmp[512];
+  // GPUEngine.cu:176-182 banner; the CUDA "cores per SM" table has no AMD entry (it would print 0)
+  snprintf(tmp, sizeof tmp, "GPU #%d %s (%dx%d cores) Grid(%dx%d)", gpuId, name, cu, 64, nbThreadGroup, nbThreadPerGroup);
+  deviceName = std::string(tmp);
+#ifdef KNG_REFERENCE_HEADER
+  initialised = true;
+#endif
+}
+
+GPUEngine::~GPUEngine() {
+  kng_destroy(ENGINE); // waits for an in-flight kernel (Kangaroo.cpp:572-634 deletes mid-flight)
+  ENGINE = NULL;
+}
+
+void GPUEngine::SetWildOffset(Int *offset) { wildOffset.Set(offset); }
+
+int GPUEngine::GetNbThread() { return nbThread; }
+int GPUEngine::GetGroupSize() { return KNG_GRP_SIZE; }
+
+int GPUEngine::GetMemory() {
+  // the reference returns int and overflows above 2 GiB (GPUEngine.h:79): saturate
+  uint64_t b = kng_memory_bytes(ENGINE);
+  return b > 0x7FFFFFFFULL ? 0x7FFFFFFF : (int)b;
+}
+
+bool GPUEngine::GetGridSize(int gpuId, int *x, int *y) {
+  if (kng_default_grid(gpuId, x, y) != KNG_OK) {
+    printf("GPUEngine: %s\n", kng_last_error());
+    return false;
+  }
+  return true;
+}
+
+void *GPUEngine::AllocatePinnedMemory(size_t size) {
+  void *p = kng_alloc_pinned(size);
+  if (!p) printf("GPUEngine: AllocatePinnedMemory: %s\n", kng_last_error());
+  return p;
+}
+void GPUEngine::FreePinnedMemory(void *buff) { kng_free_pinned(buff); }
+
+void GPUEngine::PrintCudaInfo() {
+  int n = kng_device_count();
+  if (n == 0) {
+    printf("GPUEngine: There are no available device(s) that support HIP\n");
+    return;
+  }
+  for (int i = 0; i < n; i++) {
+    char name[256] = "", arch[64] = "";
+    int cu = 0;
+    uint64_t mem = 0;
+    if (kng_device_info(i, name, sizeof name, &cu, &mem, arch, sizeof arch) != KNG_OK) continue;
+    printf("GPU #%d %s (%dx%d cores) (%s) (%.1f MB) (Multiple host threads)\n", i, name, cu, 64, arch, (double)mem / 1048576.0);
+  }
+}
+
+void GPUEngine::SetParams(uint64_t dpMask, Int *distance, Int *px, Int *py) {
+#ifdef KNG_REFERENCE_HEADER
+  this->dpMask = dpMask;
+#endif
+  uint64_t jd[KNG_NB_JUMP][2], jx[KNG_NB_JUMP][4], jy[KNG_NB_JUMP][4];
+  for (int i = 0; i < KNG_NB_JUMP; i++) {
+    memcpy(jd[i], distance[i].bits64, 16); // 128-bit jump distances (GPUEngine.cu:563-565)
+    memcpy(jx[i], px[i].bits64, 32);
+    memcpy(jy[i], py[i].bits64, 32);
+  }
+  KNG_MUST(kng_set_params(ENGINE, dpMask, &jd[0][0], &jx[0][0], &jy[0][0]), "SetParams");
+}
+
+void GPUEngine::SetKangaroos(Int *px, Int *py, Int *d) {
+  const uint64_t n = kng_nb_kangaroos(ENGINE);
+  // device distances: wild (odd index) += wildOffset mod n (GPUEngine.cu:406-411)
+  std::vector<uint64_t> dd(2 * n);
+  for (uint64_t i = 0; i < n; i++) {
+    Int dOff;
+    dOff.Set(&d[i]);
+    if (i % 2 == WILD) dOff.ModAddK1order(&wildOffset);
+    dd[2 * i] = dOff.bits64[0];
+    dd[2 * i + 1] = dOff.bits64[1];
+  }
+  KNG_MUST(kng_set_kangaroos(ENGINE, px[0].bits64, INT_STRIDE, py[0].bits64, INT_STRIDE, dd.data(), 2, n), "SetKangaroos");
+}
+
+void GPUEngine::GetKangaroos(Int *px, Int *py, Int *d) {
+  const uint64_t n = kng_nb_kangaroos(ENGINE);
+  std::vector<uint64_t> dd(2 * n);
+  KNG_MUST(kng_get_kangaroos(ENGINE, px[0].bits64, INT_STRIDE, py[0].bits64, INT_STRIDE, dd.data(), 2, n), "GetKangaroos");
+  for (uint64_t i = 0; i < n; i++) {
+    px[i].bits64[4] = 0;
+    py[i].bits64[4] = 0;
+    Int dOff;
+    dOff.SetInt32(0);
+    dOff.bits64[0] = dd[2 * i];
+    dOff.bits64[1] = dd[2 * i + 1];
+    if (i % 2 == WILD) dOff.ModSubK1order(&wildOffset); // GPUEngine.cu:477
+    d[i].Set(&dOff);
+  }
+}
+
+void GPUEngine::SetKangaroo(uint64_t kIdx, Int *px, Int *py, Int *d) {
+  Int dOff;
+  dOff.Set(d);
+  if (kIdx % 2 == WILD) dOff.ModAddK1order(&wildOffset); // GPUEngine.cu:526
+  KNG_MUST(kng_set_kangaroo(ENGINE, kIdx, px->bits64, py->bits64, dOff.bits64), "SetKangaroo");
+}
+
+bool GPUEngine::callKernel() {
+  if (kng_launch(ENGINE) != KNG_OK) {
+    printf("GPUEngine: Kernel: %s\n", kng_last_error());
+    return false;
+  }
+  return true;
+}
+
+bool GPUEngine::callKernelAndWait() {
+  if (!callKernel()) return false;
+  if (kng_wait(ENGINE, 0) != KNG_OK) {
+    printf("GPUEngine: callKernelAndWait: %s\n", kng_last_error());
+    return false;
+  }
+  return true;
+}
+
+bool GPUEngine::Launch(std::vector<ITEM> &hashFound, bool spinWait) {
+  hashFound.clear();
+  // results of the PREVIOUS kernel (GPUEngine.cu:607-676).  Nothing is outstanding on the very
+  // first call of Check.cpp:526; the reference then reads an uninitialised counter.
+  const bool had = kng_outstanding(ENGINE) == 1;
+  if (had && kng_wait(ENGINE, spinWait ? 1 : 0) != KNG_OK) {
+    printf("GPUEngine: Launch: %s\n", kng_last_error());
+    return false;
+  }
+  // start the next kernel BEFORE unpacking, so the DP copy and the host work overlap it
+  const bool ok = callKernel();
+  if (had) {
+    std::vector<kng_item> items(maxFound);
+    uint32_t nb = 0, lost = 0;
+    if (kng_drain(ENGINE, items.data(), maxFound, &nb, &lost) != KNG_OK) {
+      printf("GPUEngine: Launch: %s\n", kng_last_error());
+      return false;
+    }
+    if (lost && !lostWarning) { // GPUEngine.cu:641-648
+      printf("\nWarning, %u items lost\nHint: Search with less threads (-g) or increse dp (-d)\n", lost);
+      lostWarning = true;
+    }
+    hashFound.reserve(nb);
+    for (uint32_t i = 0; i < nb; i++) {
+      ITEM it;
+      it.kIdx = items[i].kidx;
+      it.x.SetInt32(0);
+      memcpy(it.x.bits64, items[i].x, 32);
+      it.d.SetInt32(0);
+      it.d.bits64[0] = items[i].d[0];
+      it.d.bits64[1] = items[i].d[1];
+      if (it.kIdx % 2 == WILD) it.d.ModSubK1order(&wildOffset); // GPUEngine.cu:672
+      hashFound.push_back(it);
+    }
+  }
+  return ok;
+}
