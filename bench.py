@@ -50,26 +50,26 @@ def cpu_baseline(seconds: float = 20.0) -> dict:
     _, kx, ky = hl.pubkey(KEY)
     pub = ("02" if ky % 2 == 0 else "03") + f"{kx:064X}"
     if os.path.exists(ref):
-        import pty
         import select
+        import shutil
 
         with tempfile.TemporaryDirectory() as td:
             cfg = os.path.join(td, "in80.txt")
             with open(cfg, "w") as f:
                 f.write(f"{RANGE_START:064X}\n{RANGE_START + (1 << RANGE_POWER) - 1:064X}\n{pub}\n")
-            # the status line is printf("\r[%.2f MK/s]...") without fflush (Thread.cpp:306-314): use a pty
-            master, slave = pty.openpty()
-            proc = subprocess.Popen([ref, "-t", str(cores), cfg], stdout=slave, stderr=slave, close_fds=True)
-            os.close(slave)
+            # the status line is printf("\r[%.2f MK/s]...") without fflush (Thread.cpp:306-314):
+            # unbuffer its stdout with stdbuf (LD_PRELOAD), read through a pipe, stop it after `seconds`
+            cmd = [ref, "-t", str(cores), cfg]
+            if shutil.which("stdbuf"):
+                cmd = ["stdbuf", "-o0", "-e0"] + cmd
+            proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            fd = proc.stdout.fileno()
             buf = b""
             t0 = time.time()
             while time.time() - t0 < seconds:
-                r, _, _ = select.select([master], [], [], 0.5)
+                r, _, _ = select.select([fd], [], [], 0.5)
                 if r:
-                    try:
-                        chunk = os.read(master, 65536)
-                    except OSError:
-                        break
+                    chunk = os.read(fd, 65536)
                     if not chunk:
                         break
                     buf += chunk
@@ -77,7 +77,6 @@ def cpu_baseline(seconds: float = 20.0) -> dict:
                     break
             proc.kill()
             proc.wait()
-            os.close(master)
         rates = [float(m) for m in re.findall(rb"\[([0-9.]+) MK/s\]\[GPU", buf)]
         steady = rates[3:] if len(rates) > 6 else rates  # 8-sample moving average: skip the ramp
         if steady:
