@@ -247,7 +247,7 @@ struct kng_engine {
     uint32_t max_found = 0;
     // tuning
     uint32_t group = 0; // kangaroos per lane
-    uint32_t block = 64;
+    uint32_t block = 256;
     uint32_t nsteps = KNG_NB_RUN;
     uint32_t lanes = 0;
     int cu_count = 0;
@@ -313,10 +313,12 @@ int kng_default_grid(int dev, int *x, int *y) {
 }
 
 static void choose_geometry(kng_engine *h) {
-    // lanes L = n / group.  Default group: as large as possible (cheapest inversion share)
-    // while every SIMD of the chip still gets at least one wave.
+    // lanes L = n / group.  The per-lane batch amortises one modular inversion, so bigger is
+    // cheaper -- but one wave can only issue a VALU instruction every ~5 cycles on gfx950
+    // (profiles/r01_clock_probe.txt), so every SIMD needs at least two resident waves to be
+    // kept busy.  Default: the largest group that still leaves >= 2 waves per SIMD.
     if (h->group == 0) {
-        const uint64_t want_lanes = (uint64_t)h->cu_count * 4 * 64;
+        const uint64_t want_lanes = (uint64_t)h->cu_count * 4 * 64 * 2;
         uint32_t g = KNG_GRP_SIZE;
         while (g > 16 && h->n / g < want_lanes) g >>= 1;
         h->group = g;

@@ -13,8 +13,15 @@
 //                     inverse is bit-identical; see kng_modinv.h for the one used.
 #pragma once
 
-#include <hip/hip_runtime.h>
 #include <stdint.h>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define KNG_DEV __device__ __forceinline__
+#define KNG_DEV_NOINLINE __device__ __noinline__
+#else // host build of the same arithmetic (tools/host_field_test.cpp, clang++): unit tests without a GPU
+#define KNG_DEV static inline
+#define KNG_DEV_NOINLINE static
+#endif
 
 namespace kng {
 
@@ -23,8 +30,6 @@ typedef unsigned __int128 u128;
 struct fe {
     uint64_t v[4];
 };
-
-#define KNG_DEV __device__ __forceinline__
 
 constexpr uint64_t P0 = 0xFFFFFFFEFFFFFC2FULL; // GPUMath.h:83-88
 constexpr uint64_t PX = 0xFFFFFFFFFFFFFFFFULL;
@@ -35,19 +40,25 @@ KNG_DEV fe fe_one() { return fe{{1, 0, 0, 0}}; }
 KNG_DEV bool fe_is_zero(const fe &a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3]) == 0; }
 
 // r = a - b ; if borrow r += p        (GPUMath.h:476-494)
+// On 32-bit words so that hipcc emits plain v_sub_co/v_subb_co chains (with 64-bit builtins it
+// falls back to 64-bit compares and selects: ~50 instructions per subtraction).  Adding p is
+// subtracting 2^256 - p = 2^32 + 977 modulo 2^256.
 KNG_DEV fe fe_sub(const fe &a, const fe &b) {
-    fe r;
-    unsigned long long br = 0, c = 0;
-    r.v[0] = __builtin_subcll(a.v[0], b.v[0], 0, &br);
-    r.v[1] = __builtin_subcll(a.v[1], b.v[1], br, &br);
-    r.v[2] = __builtin_subcll(a.v[2], b.v[2], br, &br);
-    r.v[3] = __builtin_subcll(a.v[3], b.v[3], br, &br);
-    const uint64_t m = 0 - (uint64_t)br; // all ones on borrow
-    r.v[0] = __builtin_addcll(r.v[0], P0 & m, 0, &c);
-    r.v[1] = __builtin_addcll(r.v[1], m, c, &c);
-    r.v[2] = __builtin_addcll(r.v[2], m, c, &c);
-    r.v[3] = __builtin_addcll(r.v[3], m, c, &c);
-    return r;
+    uint32_t r[8];
+    unsigned br = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        r[2 * i] = __builtin_subc((unsigned)a.v[i], (unsigned)b.v[i], br, &br);
+        r[2 * i + 1] = __builtin_subc((unsigned)(a.v[i] >> 32), (unsigned)(b.v[i] >> 32), br, &br);
+    }
+    const unsigned m = 0u - br; // all ones on borrow
+    unsigned c = 0;
+    r[0] = __builtin_subc(r[0], 977u & m, 0u, &c);
+    r[1] = __builtin_subc(r[1], 1u & m, c, &c);
+#pragma unroll
+    for (int i = 2; i < 8; i++) r[i] = __builtin_subc(r[i], 0u, c, &c);
+    return fe{{(uint64_t)r[0] | ((uint64_t)r[1] << 32), (uint64_t)r[2] | ((uint64_t)r[3] << 32),
+               (uint64_t)r[4] | ((uint64_t)r[5] << 32), (uint64_t)r[6] | ((uint64_t)r[7] << 32)}};
 }
 
 // 512 -> 320 -> 256 fold (GPUMath.h:840-856 / IntMod.cpp:926-942)
@@ -79,7 +90,7 @@ KNG_DEV fe fe_fold(const uint64_t w[8]) {
     return r;
 }
 
-KNG_DEV fe fe_mul(const fe &a, const fe &b) {
+KNG_DEV fe fe_mul_c64(const fe &a, const fe &b) {
     uint64_t w[8];
     // row 0
     u128 c = (u128)a.v[0] * b.v[0];
@@ -106,7 +117,7 @@ KNG_DEV fe fe_mul(const fe &a, const fe &b) {
     return fe_fold(w);
 }
 
-KNG_DEV fe fe_sqr(const fe &a) {
+KNG_DEV fe fe_sqr_c64(const fe &a) {
     // 10 distinct products: 4 squares + 6 cross terms added twice (GPUMath.h:913-1019 idea;
     // the result is the same 512-bit integer as a*a, so the fold is bit-identical)
     uint64_t w[8];
@@ -152,6 +163,77 @@ KNG_DEV fe fe_sqr(const fe &a) {
     w[7] = (uint64_t)(c >> 64) + x7;
     return fe_fold(w);
 }
+
+} // namespace kng
+
+#include "kng_mul32.h"
+
+namespace kng {
+
+#define KNG_ADDC32(x, y, ci, co) __builtin_addc((unsigned)(x), (unsigned)(y), (unsigned)(ci), (co))
+
+// Same fold on 32-bit words: S = lo + hi*K exactly, T = S >> 256 (<= K), r = (S mod 2^256) + T*K
+// mod 2^256 -- the integer the reference computes (last carry dropped).
+KNG_DEV fe fe_fold32(const uint32_t w[16]) {
+    uint64_t q[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) q[j] = (uint64_t)w[8 + j] * 977u + w[j]; // < 2^43
+    uint32_t t[9];
+    unsigned c = 0;
+    // S = sum q_j 2^(32j) + sum hi_j 2^(32(j+1)) : two carry chains
+    t[0] = (uint32_t)q[0];
+#pragma unroll
+    for (int j = 1; j < 8; j++) t[j] = KNG_ADDC32((uint32_t)q[j], w[8 + j - 1], c, &c);
+    t[8] = KNG_ADDC32(0u, w[15], c, &c);
+    uint32_t top = c;
+    c = 0;
+#pragma unroll
+    for (int j = 1; j < 9; j++) t[j] = KNG_ADDC32(t[j], (uint32_t)(q[j - 1] >> 32), c, &c);
+    top += c; // T = top*2^32 + t[8] <= 2^32 + 977
+    // T*K = t8*977 + (t8 << 32) + top*977*2^32 + top*2^64
+    const uint64_t f = (uint64_t)t[8] * 977u;
+    uint32_t a1 = KNG_ADDC32((uint32_t)(f >> 32), t[8], 0, &c);
+    uint32_t a2 = c;
+    a1 = KNG_ADDC32(a1, top * 977u, 0, &c);
+    a2 += c + top;
+    uint32_t r[8];
+    c = 0;
+    r[0] = KNG_ADDC32(t[0], (uint32_t)f, c, &c);
+    r[1] = KNG_ADDC32(t[1], a1, c, &c);
+    r[2] = KNG_ADDC32(t[2], a2, c, &c);
+#pragma unroll
+    for (int j = 3; j < 8; j++) r[j] = KNG_ADDC32(t[j], 0u, c, &c);
+    // final carry dropped on purpose (IntMod.cpp:944)
+    return fe{{(uint64_t)r[0] | ((uint64_t)r[1] << 32), (uint64_t)r[2] | ((uint64_t)r[3] << 32),
+               (uint64_t)r[4] | ((uint64_t)r[5] << 32), (uint64_t)r[6] | ((uint64_t)r[7] << 32)}};
+}
+
+KNG_DEV void fe_to32(uint32_t r[8], const fe &a) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        r[2 * i] = (uint32_t)a.v[i];
+        r[2 * i + 1] = (uint32_t)(a.v[i] >> 32);
+    }
+}
+
+KNG_DEV fe fe_mul_c32(const fe &a, const fe &b) {
+    uint32_t x[8], y[8], w[16];
+    fe_to32(x, a);
+    fe_to32(y, b);
+    mul_wide32(w, x, y);
+    return fe_fold32(w);
+}
+
+#ifndef KNG_MUL_IMPL
+#define KNG_MUL_IMPL 32
+#endif
+#if KNG_MUL_IMPL == 32
+KNG_DEV fe fe_mul(const fe &a, const fe &b) { return fe_mul_c32(a, b); }
+KNG_DEV fe fe_sqr(const fe &a) { return fe_mul_c32(a, a); }
+#else
+KNG_DEV fe fe_mul(const fe &a, const fe &b) { return fe_mul_c64(a, b); }
+KNG_DEV fe fe_sqr(const fe &a) { return fe_sqr_c64(a); }
+#endif
 
 // full reduction of a value in [0,2^256) into [0,p)
 KNG_DEV fe fe_canon(const fe &a) {

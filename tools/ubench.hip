@@ -55,10 +55,12 @@ __global__ void k_field(uint64_t *out, uint64_t seed, int iters) {
     fe a{{seed + t, seed * 3 + t, seed * 5 + 1, seed * 7 + 2}};
     fe b{{seed * 11 + t, seed * 13 + 5, seed * 17 + t, seed * 19 + 3}};
     for (int i = 0; i < iters; i++) {
-        if (OP == 0) { a = fe_mul(a, b); b = fe_mul(b, a); }
-        else if (OP == 1) { a = fe_sqr(a); b = fe_sqr(b); }
-        else if (OP == 2) { a = fe_sub(a, b); b = fe_sub(b, a); }
-        else if (OP == 3) { a = fe_inv(a); b = fe_sub(b, a); }
+        if (OP == 0) { a = fe_mul_c32(a, b); b = fe_mul_c32(b, a); }
+        else if (OP == 1) { a = fe_mul_c64(a, b); b = fe_mul_c64(b, a); }
+        else if (OP == 2) { a = fe_sqr_c64(a); b = fe_sqr_c64(b); }
+        else if (OP == 3) { a = fe_sub(a, b); b = fe_sub(b, a); }
+        else if (OP == 4) { a = fe_inv(a); b = fe_sub(b, a); }
+        else if (OP == 5) { a = fe_inv_fermat(a); b = fe_sub(b, a); }
     }
     out[t] = a.v[0] ^ a.v[1] ^ a.v[2] ^ a.v[3] ^ b.v[0] ^ b.v[3];
 }
@@ -110,21 +112,23 @@ int main() {
         }
     }
     printf("\n== 256-bit field ops, chip-wide (2 ops per iteration per lane) ==\n");
-    const char *fnames[] = {"fe_mul", "fe_sqr", "fe_sub", "fe_inv"};
+    const char *fnames[] = {"fe_mul_c32(asm comba)", "fe_mul_c64(compiler)", "fe_sqr_c64(compiler)", "fe_sub", "fe_inv(safegcd30)", "fe_inv_fermat"};
     for (int wps = 1; wps <= 4; wps *= 2) {
         const int blocks = cus * wps * 4, threads = 64;
-        for (int op = 0; op < 4; op++) {
-            const int iters = op == 3 ? 8 : 2000;
+        for (int op = 0; op < 6; op++) {
+            const int iters = op >= 4 ? 8 : 2000;
             double ms;
             switch (op) {
             case 0: ms = time_ms([&] { hipLaunchKernelGGL(k_field<0>, dim3(blocks), dim3(threads), 0, 0, out, 12345ull, iters); }); break;
             case 1: ms = time_ms([&] { hipLaunchKernelGGL(k_field<1>, dim3(blocks), dim3(threads), 0, 0, out, 12345ull, iters); }); break;
             case 2: ms = time_ms([&] { hipLaunchKernelGGL(k_field<2>, dim3(blocks), dim3(threads), 0, 0, out, 12345ull, iters); }); break;
-            default: ms = time_ms([&] { hipLaunchKernelGGL(k_field<3>, dim3(blocks), dim3(threads), 0, 0, out, 12345ull, iters); }); break;
+            case 3: ms = time_ms([&] { hipLaunchKernelGGL(k_field<3>, dim3(blocks), dim3(threads), 0, 0, out, 12345ull, iters); }); break;
+            case 4: ms = time_ms([&] { hipLaunchKernelGGL(k_field<4>, dim3(blocks), dim3(threads), 0, 0, out, 12345ull, iters); }); break;
+            default: ms = time_ms([&] { hipLaunchKernelGGL(k_field<5>, dim3(blocks), dim3(threads), 0, 0, out, 12345ull, iters); }); break;
             }
-            const double ops = (double)blocks * threads * iters * (op == 3 ? 1 : 2);
-            const double cyc_per_wave_op = ms * 1e-3 * ghz * 1e9 / ((double)wps * iters * (op == 3 ? 1 : 2));
-            printf("  %-7s waves/SIMD %d : %8.3f ms  %9.2f Gop/s chip  %8.1f cycles per wave-op per SIMD\n", fnames[op], wps, ms, ops / ms / 1e6, cyc_per_wave_op);
+            const double ops = (double)blocks * threads * iters * (op >= 4 ? 1 : 2);
+            const double cyc_per_wave_op = ms * 1e-3 * ghz * 1e9 / ((double)wps * iters * (op >= 4 ? 1 : 2));
+            printf("  %-22s waves/SIMD %d : %8.3f ms  %9.2f Gop/s chip  %8.1f cycles per wave-op per SIMD\n", fnames[op], wps, ms, ops / ms / 1e6, cyc_per_wave_op);
         }
     }
     return 0;
