@@ -115,23 +115,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # torch is plumbing here: rendezvous/barrier over RCCL and the cross-rank max of the timings
+    import torch  # noqa: F401
+
+    from kangaroo_amd.dist import Ranks, timed_steps, whole_job_rate
+
+    ranks = Ranks(backend="nccl")
+    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
     if world != args.gpus and world > 1:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
-    n_gpus = max(world, 1)
-
-    # torch is plumbing here: rendezvous/barrier over RCCL and the cross-rank max of the timings
-    import torch
-
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
 
     import numpy as np
 
@@ -149,7 +142,7 @@ def main():
     else:
         gx, gy = k.default_grid(dev)  # 2*CU x 128 (GPUEngine.cu:299-303)
     n = gx * gy * k.KNG_GRP_SIZE
-    total_rw = n * n_gpus
+    total_rw = ranks.total_kangaroos(n)
     dp = hl.suggest_dp(RANGE_POWER, total_rw)
     jd, jx, jy, javg = hl.jump_table(RANGE_POWER)
     _, kx, ky = hl.pubkey(KEY)
@@ -159,7 +152,7 @@ def main():
     _, ksx, ksy = hl.point_add((kx, ky), (sx, P - sy))
 
     t0 = time.time()
-    x, y, d_true, woff = hl.create_herd(n, RANGE_POWER, (ksx, ksy), first_type=0, seed=0xBEEF + rank)
+    x, y, d_true, woff = hl.create_herd(n, RANGE_POWER, (ksx, ksy), first_type=0, seed=ranks.herd_seed(0xBEEF))
     t_herd = time.time() - t0
     opts = {}
     if args.group:
@@ -178,11 +171,6 @@ def main():
             f"group {eng.get_option('group')} lanes {eng.get_option('lanes')} "
             f"({eng.GetMemory() / 1048576.0:.1f} MB); herd built in {t_herd:.1f}s, uploaded in {t_up:.1f}s")
 
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     # warmup: W full steps
     for _ in range(args.warmup):
         eng.callKernel()
@@ -190,30 +178,26 @@ def main():
         eng.drain(raw=True)
 
     kernel_ms = []
-    dps = 0
-    lost = 0
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    counts = {"dps": 0, "lost": 0}
+
+    def step(i):
         eng.callKernel()
-        # drain the previous step's DPs while this launch runs (async drain, DP buffers are double-buffered)
-        if kernel_ms:
-            dps += len(eng.drain(raw=True))
-            lost += eng.lastLost
+        # drain the previous step's DPs while this launch runs (DP buffers are double-buffered)
+        if i:
+            counts["dps"] += len(eng.drain(raw=True))
+            counts["lost"] += eng.lastLost
         eng.wait()
         kernel_ms.append(eng.last_kernel_ms())
-    dps += len(eng.drain(raw=True))
-    lost += eng.lastLost
-    sync()
-    elapsed = time.perf_counter() - t0
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def finish():
+        counts["dps"] += len(eng.drain(raw=True))
+        counts["lost"] += eng.lastLost
+
+    elapsed = timed_steps(ranks, step, finish, args.steps)  # barrier+sync, K steps, barrier+sync, max over ranks
+    dps, lost = counts["dps"], counts["lost"]
 
     jumps_per_step = n * k.KNG_NB_RUN
-    value = n_gpus * jumps_per_step * args.steps / elapsed / 1e6  # MK/s, whole job
+    value = whole_job_rate(ranks, jumps_per_step, args.steps, elapsed) / 1e6  # MK/s, whole job
     kms = float(np.mean(kernel_ms))
     achieved = jumps_per_step * ALG_BYTES_PER_JUMP / (kms * 1e-3) / 1e9  # GB/s, per GPU
     traffic = None
@@ -260,9 +244,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         except Exception as e:  # the baseline is reported, never required
             out["cpu_baseline"] = {"value": None, "unit": "MK/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
 
