@@ -9,7 +9,7 @@ SURVEY App. D.3).
 import numpy as np
 import pytest
 
-from helpers import (M128, N_ORDER, array_to_ints, device_distances, dp_multiset, ints_to_array, walk_fixture)
+from helpers import (M128, N_ORDER, P, array_to_ints, device_distances, dp_multiset, ints_to_array, walk_fixture)
 
 pytestmark = pytest.mark.gpu
 
@@ -78,6 +78,60 @@ def test_primitives_random_vs_oracle(kng, orc, op):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("op", ["mul29", "sub29", "rx29", "ry29", "inv29"])
+def test_radix29_primitives_vs_bigint(kng, op):
+    """The carry-free 9x29-bit arithmetic of walk policy 29: canonical results against Python integers,
+    on random operands, operands around p / 2^256 (non-canonical inputs) and tiny operands."""
+    from helpers import P
+
+    rng = np.random.default_rng(99)
+    n = 20000 if op != "inv29" else 4096
+    a = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    b = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    a[::97, 1:] = np.uint64(0xFFFFFFFFFFFFFFFF)   # >= p or just below
+    b[::89, 1:] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    a[::101, 1:] = 0
+    b[::103, 1:] = 0
+    edge = [0, 1, 2, P - 1, P, P + 1, (1 << 256) - 1, (1 << 256) - 0x1000003D1 + 5, 1 << 255, (1 << 232) - 1]
+    for i, v in enumerate(edge):
+        a[i] = ints_to_array([v])[0]
+        b[(i * 7) % len(edge)] = ints_to_array([v])[0]
+    got = array_to_ints(kng.test_fieldop(op, a, b))
+    ai, bi = array_to_ints(a), array_to_ints(b)
+    f = {"mul29": lambda x, y: x * y % P, "sub29": lambda x, y: (x - y) % P, "rx29": lambda x, y: (x * x - y - x) % P,
+         "ry29": lambda x, y: ((x - y) * x - y) % P, "inv29": lambda x, y: pow(x % P, -1, P) if x % P else 0}[op]
+    want = [f(x, y) for x, y in zip(ai, bi)]
+    assert got == want
+
+
+def test_radix29_full_jump_sequence(kng):
+    """One complete jump in the exact operation order of the policy-29 kernel, with every
+    intermediate checked (this composition exposed a hipcc miscompile of fe29_canon that the
+    single-operation tests above do not see)."""
+    from helpers import P
+
+    rng = np.random.default_rng(3)
+    n = 4096
+    a = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    b = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    a[:, 3] >>= np.uint64(1)
+    b[:, 3] >>= np.uint64(1)
+    A, B = array_to_ints(a), array_to_ints(b)
+    exp = {k: [] for k in ("jump29_dx", "jump29_inv", "jump29_s", "jump29_rx", "jump29_ry", "jump29")}
+    for x, jx in zip(A, B):
+        y = (jx - x) % P
+        jy = ((jx ^ 1) & ((1 << 255) - 1)) % P
+        dx = (x - jx) % P
+        inv = pow(dx, -1, P)
+        s = (y - jy) * inv % P
+        rx = (s * s - jx - x) % P
+        ry = (s * (x - rx) - y) % P
+        for k_, v in zip(exp, (dx, inv, s, rx, ry, (rx - ry) % P)):
+            exp[k_].append(v)
+    for op, want in exp.items():
+        assert array_to_ints(kng.test_fieldop(op, a, b)) == want, op
+
+
 def test_fieldop_empty(kng):
     e = np.zeros((0, 4), dtype=np.uint64)
     assert kng.test_fieldop("modmul", e, e).shape == (0, 4)
@@ -109,11 +163,12 @@ def _run_check_protocol(kng, w, jd, jx, jy, grid, launches, **opts):
 @pytest.mark.parametrize("name,grid,launches", [("walk_check64", (2, 1), 1), ("walk_80", (1, 1), 1),
                                                 ("walk_125", (1, 1), 2)])
 @pytest.mark.parametrize("group", [1, 4, 128])
-def test_walk_matches_reference_vectors(kng, orc, golden, name, grid, launches, group):
+@pytest.mark.parametrize("arith", [29, 32])
+def test_walk_matches_reference_vectors(kng, orc, golden, name, grid, launches, group, arith):
     w = walk_fixture(golden[name])
     assert w["nsteps"] == 64 * launches
     jd, jx, jy, _ = orc.jump_table(w["range_power"])
-    end, dps = _run_check_protocol(kng, w, jd, jx, jy, grid, launches, group=group)
+    end, dps = _run_check_protocol(kng, w, jd, jx, jy, grid, launches, group=group, arith=arith)
     assert end == w["end"]
     assert dp_multiset(dps) == dp_multiset(w["dps"])
 
@@ -144,14 +199,15 @@ def _seeded_herd(orc, n, range_power, seed):
     ((2, 4), 128, 64, 2, 0),     # dp=0: every jump is a DP -> 64*n points, exercises max_found clamp
     ((8, 4), 64, 64, 1, 7),
 ])
-def test_walk_vs_oracle(kng, orc, grid, group, block, launches, dp):
+@pytest.mark.parametrize("arith", [29, 32])
+def test_walk_vs_oracle(kng, orc, grid, group, block, launches, dp, arith):
     n = grid[0] * grid[1] * 128
     rp = 72
     x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=grid[0] * 100 + group)
     jd, jx, jy, _ = orc.jump_table(rp)
     mask = orc.dp_mask(dp)
     max_found = 1 << 16
-    eng = kng.GPUEngine(grid[0], grid[1], 0, max_found, group=group, block=block)
+    eng = kng.GPUEngine(grid[0], grid[1], 0, max_found, group=group, block=block, arith=arith)
     eng.SetParams(mask, jd, jx, jy)
     eng.SetWildOffset(wild_offset)
     eng.SetKangaroos(x, y, ints_to_array(true_d))
@@ -177,7 +233,8 @@ def test_walk_vs_oracle(kng, orc, grid, group, block, launches, dp):
     eng.close()
 
 
-def test_set_get_roundtrip_and_single_overwrite(kng, orc):
+@pytest.mark.parametrize("arith", [29, 32])
+def test_set_get_roundtrip_and_single_overwrite(kng, orc, arith):
     """SetKangaroos/GetKangaroos are exact inverses incl. the wild offset (GPUEngine.cu:381-480);
     SetKangaroo (GPUEngine.cu:483-538) lands after an in-flight launch."""
     grid = (2, 3)
@@ -185,7 +242,7 @@ def test_set_get_roundtrip_and_single_overwrite(kng, orc):
     rp = 125
     x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=7)
     jd, jx, jy, _ = orc.jump_table(rp)
-    eng = kng.GPUEngine(grid[0], grid[1], 0, 4096, group=16)
+    eng = kng.GPUEngine(grid[0], grid[1], 0, 4096, group=16, arith=arith)
     eng.SetParams(orc.dp_mask(10), jd, jx, jy)
     eng.SetWildOffset(wild_offset)
     eng.SetKangaroos(x, y, ints_to_array(true_d))
@@ -238,3 +295,80 @@ def test_default_grid_and_banner(kng):
     assert eng.deviceName.startswith("GPU #0 ") and "Grid(1x1)" in eng.deviceName
     assert eng.GetGroupSize() == 128 and eng.GetNbThread() == 1 and eng.GetMemory() > 0
     eng.close()
+
+
+# ------------------------------------------------------------------ BASELINE.json full size
+@pytest.mark.parametrize("arith", [32, 29])
+def test_full_size_herd_properties(kng, orc, arith):
+    """The headline herd (reference default grid 2*CU x 128 -> 2^23 kangaroos, 80-bit range, auto DP)
+    for three launches, checked through size-independent properties:
+      * the group invariant of the walk: after any number of jumps every kangaroo still sits at
+        d*G (tame) / K + d*G (wild) -- verified with the oracle on a random sample of the herd,
+      * every reported DP has its masked bits clear, is reported by an existing kangaroo, and its
+        (x, d) satisfies the same invariant,
+      * every kangaroo advanced: total distance gained equals the sum of 192 table jumps in range,
+      * a sampled sub-herd replayed by the oracle for 192 jumps gives bit-identical (x, y, d)."""
+    import kangaroo_amd.hostlib as hl
+
+    gx, gy = kng.default_grid(0)
+    n = gx * gy * 128
+    rp = 80
+    key = (0xB60E83280258A40F9CDF1649744D730D6E939DE92A2B << 80) + 0xC0FFEE123456789ABCD
+    _, kx, ky = hl.pubkey(key)
+    _, sx, sy = hl.pubkey(0xB60E83280258A40F9CDF1649744D730D6E939DE92A2B << 80)
+    _, ksx, ksy = hl.point_add((kx, ky), (sx, P - sy))  # keyToSearch, Kangaroo.cpp:892-909
+    x, y, d_true, woff = hl.create_herd(n, rp, (ksx, ksy), seed=2024)
+    dev_d = hl.to_device_distances(d_true, woff)
+    dp = hl.suggest_dp(rp, n)
+    assert dp == 14
+    jd, jx, jy, _ = hl.jump_table(rp)
+    mask = hl.dp_mask(dp)
+    launches = 3
+    rng = np.random.default_rng(5)
+    sample = np.sort(rng.choice(n, size=1536, replace=False))
+    with kng.GPUEngine(gx, gy, 0, 65536 * 2, arith=arith) as eng:
+        eng.SetParams(mask, jd, jx, jy)
+        eng.SetWildOffset(woff)
+        eng.SetKangaroos(x, y, dev_d)
+        dps = []
+        for _ in range(launches):
+            eng.callKernel()
+            eng.wait()
+            dps.append(eng.drain(raw=True))
+            assert eng.lastLost == 0
+        gx_, gy_, gd_ = eng.GetKangaroos(raw=True)
+    dps = np.concatenate(dps)
+    # DP rate: 2^23 * 192 jumps / 2^14
+    expect = n * 64 * launches / 2 ** dp
+    assert 0.9 * expect < len(dps) < 1.1 * expect
+    assert np.all((dps["x"][:, 3] & np.uint64(mask)) == 0)
+    assert int(dps["kidx"].max()) < n
+
+    def check_invariant(xs, ys, dd, kidx):
+        true_d = hl.to_true_distances(np.ascontiguousarray(dd), woff, np.ascontiguousarray(kidx))
+        # oracle: tame d*G, wild K + d*G
+        ox = np.zeros_like(xs)
+        oy = np.zeros_like(xs)
+        for i in range(len(kidx)):
+            if int(kidx[i]) & 1:
+                orc.lib.orc_pubkey_add(ox[i], oy[i], true_d[i], ints_to_array([ksx])[0], ints_to_array([ksy])[0])
+            else:
+                orc.lib.orc_pubkey(ox[i], oy[i], true_d[i])
+        assert np.array_equal(ox, xs)
+        if ys is not None:
+            assert np.array_equal(oy, ys)
+
+    check_invariant(gx_[sample], gy_[sample], gd_[sample], sample.astype(np.uint64))
+    pick = rng.choice(len(dps), size=512, replace=False)
+    check_invariant(dps["x"][pick], None, dps["d"][pick], dps["kidx"][pick])
+    # distances only ever grow by table jumps: 192 jumps of at most max(jd) each
+    gained = gd_[sample].astype(object)[:, 0] + (gd_[sample].astype(object)[:, 1] << 64) - (
+        dev_d[sample].astype(object)[:, 0] + (dev_d[sample].astype(object)[:, 1] << 64))
+    jmax = max(array_to_ints(jd))
+    jmin = min(array_to_ints(jd))
+    assert all(192 * jmin <= int(g) <= 192 * jmax for g in gained)
+    # bit-exact replay of a contiguous sub-herd by the oracle (walks are independent)
+    sub = slice(4096, 4096 + 2048)
+    ox, oy, od = x[sub].copy(), y[sub].copy(), dev_d[sub].copy()
+    orc.walk(ox, oy, od, 64 * launches, jd, jx, jy, mask, dp_cap=0)
+    assert np.array_equal(gx_[sub], ox) and np.array_equal(gy_[sub], oy) and np.array_equal(gd_[sub], od)
