@@ -6,10 +6,14 @@ single-kangaroo overwrite, Launch; GetKangaroos; Launch, then compare every (x, 
 list -- but with an exact DP multiset comparison (the reference never checks for extra GPU DPs,
 SURVEY App. D.3).
 """
+import os
+
 import numpy as np
 import pytest
 
 from helpers import (M128, N_ORDER, P, array_to_ints, device_distances, dp_multiset, ints_to_array, walk_fixture)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -372,3 +376,73 @@ def test_full_size_herd_properties(kng, orc, arith):
     ox, oy, od = x[sub].copy(), y[sub].copy(), dev_d[sub].copy()
     orc.walk(ox, oy, od, 64 * launches, jd, jx, jy, mask, dp_cap=0)
     assert np.array_equal(gx_[sub], ox) and np.array_equal(gy_[sub], oy) and np.array_equal(gd_[sub], od)
+
+
+# ------------------------------------------------------------------ end to end: actually solve keys
+IN_TXT_RANGE_END = 0xFFFFFFFFFFFFFF          # the reference's shipped 56-bit known-answer input (in.txt)
+IN_TXT_PUBKEY = "02E9F43F810784FF1E91D8BC7C4FF06BFEE935DA71D7350734C3472FE305FEF82A"
+IN_TXT_ANSWER = 0x378ABDEC51BC5D             # README.md:331-357
+
+
+def _decompress(pub_hex):
+    x = int(pub_hex[2:], 16)
+    y = pow((x * x * x + 7) % P, (P + 1) // 4, P)
+    if (y & 1) != (int(pub_hex[:2], 16) & 1):
+        y = P - y
+    return x, y
+
+
+def test_solve_in_txt_with_python_host(kng):
+    """Kangaroo collision search driven from Python on the engine: tame/wild DPs into a dict, a
+    tame-wild collision on x gives the key (Kangaroo.cpp:218-253).  Known answer of in.txt."""
+    import kangaroo_amd.hostlib as hl
+
+    rp = 56
+    kx, ky = _decompress(IN_TXT_PUBKEY)            # range start is 0: keyToSearch = K
+    gx, gy = 32, 128
+    n = gx * gy * 128                               # 2^19 kangaroos
+    x, y, d_true, woff = hl.create_herd(n, rp, (kx, ky), seed=11)
+    jd, jx, jy, _ = hl.jump_table(rp)
+    dp = 9
+    table = {}
+    found = None
+    with kng.GPUEngine(gx, gy, 0, 65536 * 2) as eng:
+        eng.SetParams(hl.dp_mask(dp), jd, jx, jy)
+        eng.SetWildOffset(woff)
+        eng.SetKangaroos(x, y, hl.to_device_distances(d_true, woff))
+        eng.callKernel()
+        for launch in range(400):                   # expected ~2^29.1 jumps = 2^26 per launch -> ~10 launches
+            items = eng.Launch()                    # previous kernel's DPs (true distances), next kernel started
+            for it in items:
+                xx = tuple(int(v) for v in it["x"])
+                kind = int(it["kidx"]) & 1
+                dist = sum(int(v) << (64 * i) for i, v in enumerate(it["d"]))
+                other = table.get(xx)
+                if other is None:
+                    table[xx] = (kind, dist)
+                elif other[0] != kind:
+                    dt, dw = (dist, other[1]) if kind == 0 else (other[1], dist)
+                    for cand in ((dt - dw) % N_ORDER, (dt + dw) % N_ORDER, (-dt - dw) % N_ORDER, (dw - dt) % N_ORDER):
+                        if cand <= IN_TXT_RANGE_END and hl.pubkey(cand)[1:] == (kx, ky):
+                            found = cand
+                    if found is not None:
+                        break
+            if found is not None:
+                break
+        eng.wait()
+    assert found == IN_TXT_ANSWER
+    assert launch < 200
+
+
+def test_reference_program_solves_in_txt_on_our_engine(tmp_path):
+    """The unmodified reference program (oracle/_ref/kangaroo_hip = reference host code + our
+    GPUEngine) solving its own shipped known-answer input on the MI355X."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "kangaroo_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/kangaroo_hip not built (needs /root/reference at build time)")
+    cfg = tmp_path / "in.txt"
+    cfg.write_text("0\n%X\n%s\n" % (IN_TXT_RANGE_END, IN_TXT_PUBKEY))
+    out = subprocess.run([exe, "-t", "0", "-gpu", "-g", "16,128", str(cfg)], capture_output=True, text=True, timeout=300)
+    assert "Priv: 0x%X" % IN_TXT_ANSWER in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
