@@ -446,3 +446,20 @@ def test_reference_program_solves_in_txt_on_our_engine(tmp_path):
     cfg.write_text("0\n%X\n%s\n" % (IN_TXT_RANGE_END, IN_TXT_PUBKEY))
     out = subprocess.run([exe, "-t", "0", "-gpu", "-g", "16,128", str(cfg)], capture_output=True, text=True, timeout=300)
     assert "Priv: 0x%X" % IN_TXT_ANSWER in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
+
+
+def test_reference_program_solves_64bit_range_on_our_engine(tmp_path):
+    """BASELINE.json configs[1]: the reference's shipped 64-bit known-answer input (VC_CUDA8/in64.txt,
+    answer README.md:194-195) solved by the unmodified reference program on our engine."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "kangaroo_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/kangaroo_hip not built (needs /root/reference at build time)")
+    cfg = tmp_path / "in64.txt"
+    cfg.write_text("5B3F38AF935A3640D158E871CE6E9666DB862636383386EE0000000000000000\n"
+                   "5B3F38AF935A3640D158E871CE6E9666DB862636383386EEFFFFFFFFFFFFFFFF\n"
+                   "03BB113592002132E6EF387C3AEBC04667670D4CD40B2103C7D0EE4969E9FF56E4\n")
+    out = subprocess.run([exe, "-t", "0", "-gpu", "-g", "64,128", str(cfg)], capture_output=True, text=True, timeout=900)
+    assert "Priv: 0x5B3F38AF935A3640D158E871CE6E9666DB862636383386EE510F18CCC3BD72EB" in out.stdout, \
+        out.stdout[-2000:] + out.stderr[-500:]
