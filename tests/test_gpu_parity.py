@@ -463,3 +463,79 @@ def test_reference_program_solves_64bit_range_on_our_engine(tmp_path):
     out = subprocess.run([exe, "-t", "0", "-gpu", "-g", "64,128", str(cfg)], capture_output=True, text=True, timeout=900)
     assert "Priv: 0x5B3F38AF935A3640D158E871CE6E9666DB862636383386EE510F18CCC3BD72EB" in out.stdout, \
         out.stdout[-2000:] + out.stderr[-500:]
+
+
+def _run_until_saves(cmd, n_saves, max_seconds):
+    """Run the reference program unbuffered, return its output once `n_saves` work-file saves finished."""
+    import select
+    import shutil
+    import subprocess
+    import time
+
+    if shutil.which("stdbuf"):
+        cmd = ["stdbuf", "-o0", "-e0"] + cmd
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    fd = proc.stdout.fileno()
+    buf = b""
+    t0 = time.time()
+    while time.time() - t0 < max_seconds:
+        r, _, _ = select.select([fd], [], [], 0.5)
+        if r:
+            chunk = os.read(fd, 65536)
+            if not chunk:
+                break
+            buf += chunk
+        if buf.count(b"done [") >= n_saves or proc.poll() is not None:
+            break
+    proc.kill()
+    proc.wait()
+    return buf.decode(errors="replace")
+
+
+def test_reference_workfile_roundtrip_125bit_on_our_engine(tmp_path, orc):
+    """BASELINE.json configs[4] on one GPU: 125-bit (maximum) range, `-ws -w f -wi 3` save through
+    GetKangaroos, `-winfo` / `-wcheck` of the file, `-i f` restore through SetKangaroos -- all by the
+    unmodified reference program (Backup.cpp, Check.cpp) on our engine -- plus an independent check of
+    the saved kangaroos: every sampled (x, y, d) satisfies (x,y) = d*G (tame) / K + d*G (wild)."""
+    import re
+    import subprocess
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "kangaroo_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/kangaroo_hip not built (needs /root/reference at build time)")
+    cfg = tmp_path / "in125.txt"
+    cfg.write_text("0\n1FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF\n%s\n" % IN_TXT_PUBKEY)
+    f1, f2 = str(tmp_path / "a.work"), str(tmp_path / "b.work")
+    nk = 16 * 128 * 128
+    out = _run_until_saves([exe, "-t", "0", "-gpu", "-g", "16,128", "-d", "12", "-ws", "-w", f1, "-wi", "3", str(cfg)], 2, 120)
+    assert out.count("done [") >= 1, out[-1500:]
+    info = subprocess.run([exe, "-winfo", f1], capture_output=True, text=True, timeout=120).stdout
+    assert re.search(r"Kangaroos\s*:\s*%d\b" % nk, info), info
+    count1 = int(re.search(r"Count\s*:\s*(\d+)", info).group(1))
+    chk = subprocess.run([exe, "-wcheck", f1], capture_output=True, text=True, timeout=600).stdout
+    assert "100.000% OK" in chk, chk[-500:]
+
+    # the kangaroo section is the tail of the file: u64 count, then count x (32 B x, 32 B y, 32 B d)  (Backup.cpp:525-546)
+    raw = np.fromfile(f1, dtype=np.uint8)
+    tail = raw[len(raw) - nk * 96:].reshape(nk, 96)
+    assert int(np.frombuffer(raw[len(raw) - nk * 96 - 8:len(raw) - nk * 96].tobytes(), dtype=np.uint64)[0]) == nk
+    recs = np.frombuffer(tail.tobytes(), dtype=np.uint64).reshape(nk, 12)
+    kx, ky = _decompress(IN_TXT_PUBKEY)
+    rng = np.random.default_rng(8)
+    for i in rng.choice(nk, size=256, replace=False):
+        x, y, d = recs[i, 0:4], recs[i, 4:8], np.ascontiguousarray(recs[i, 8:12])
+        ox, oy = np.zeros(4, np.uint64), np.zeros(4, np.uint64)
+        if i & 1:
+            orc.lib.orc_pubkey_add(ox, oy, d, ints_to_array([kx])[0], ints_to_array([ky])[0])
+        else:
+            orc.lib.orc_pubkey(ox, oy, d)
+        assert np.array_equal(ox, x) and np.array_equal(oy, y), f"saved kangaroo {i} is not at its distance"
+
+    # restore (-i) and keep going: the count grows, the herd size stays, the new file checks again
+    out = _run_until_saves([exe, "-t", "0", "-gpu", "-g", "16,128", "-i", f1, "-ws", "-w", f2, "-wi", "3"], 1, 120)
+    assert "done [" in out, out[-1500:]
+    info2 = subprocess.run([exe, "-winfo", f2], capture_output=True, text=True, timeout=120).stdout
+    assert re.search(r"Kangaroos\s*:\s*%d\b" % nk, info2), info2
+    assert int(re.search(r"Count\s*:\s*(\d+)", info2).group(1)) > count1
+    chk2 = subprocess.run([exe, "-wcheck", f2], capture_output=True, text=True, timeout=600).stdout
+    assert "100.000% OK" in chk2, chk2[-500:]
