@@ -14,9 +14,11 @@
 #include "GPU/GPUEngine.h"
 #include "kangaroo_hip.h"
 #define ENGINE (*reinterpret_cast<kng_engine **>(&this->inputKangaroo))
+#define ITEMBUF (*reinterpret_cast<kng_item **>(&this->outputItemPinned))
 #else
 #include "GPUEngine.h"
 #define ENGINE (this->engine)
+#define ITEMBUF (this->itemBuf)
 #endif
 
 #include <cstdio>
@@ -47,9 +49,13 @@ GPUEngine::GPUEngine(int nbThreadGroup, int nbThreadPerGroup, int gpuId, uint32_
   this->lostWarning = false;
   wildOffset.SetInt32(0);
   ENGINE = NULL;
+  ITEMBUF = NULL;
   kng_engine *h = NULL;
   KNG_MUST(kng_create(gpuId, nbThreadGroup, nbThreadPerGroup, maxFound, &h), "kng_create");
   ENGINE = h;
+  // host landing buffer for one launch's DPs, allocated once (pinned)
+  ITEMBUF = (kng_item *)kng_alloc_pinned((size_t)maxFound * sizeof(kng_item));
+  if (!ITEMBUF) die("kng_alloc_pinned");
   char name[256] = "", arch[64] = "";
   int cu = 0;
   kng_device_info(gpuId, name, sizeof name, &cu, NULL, arch, sizeof arch);
@@ -65,6 +71,8 @@ GPUEngine::GPUEngine(int nbThreadGroup, int nbThreadPerGroup, int gpuId, uint32_
 GPUEngine::~GPUEngine() {
   kng_destroy(ENGINE); // waits for an in-flight kernel (Kangaroo.cpp:572-634 deletes mid-flight)
   ENGINE = NULL;
+  kng_free_pinned(ITEMBUF);
+  ITEMBUF = NULL;
 }
 
 void GPUEngine::SetWildOffset(Int *offset) { wildOffset.Set(offset); }
@@ -187,9 +195,9 @@ bool GPUEngine::Launch(std::vector<ITEM> &hashFound, bool spinWait) {
   // start the next kernel BEFORE unpacking, so the DP copy and the host work overlap it
   const bool ok = callKernel();
   if (had) {
-    std::vector<kng_item> items(maxFound);
+    kng_item *items = ITEMBUF;
     uint32_t nb = 0, lost = 0;
-    if (kng_drain(ENGINE, items.data(), maxFound, &nb, &lost) != KNG_OK) {
+    if (kng_drain(ENGINE, items, maxFound, &nb, &lost) != KNG_OK) {
       printf("GPUEngine: Launch: %s\n", kng_last_error());
       return false;
     }

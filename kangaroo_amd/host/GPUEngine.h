@@ -56,6 +56,7 @@ private:
   int nbThread;
   int nbThreadPerGroup;
   kng_engine *engine; // the whole device side lives behind the C ABI
+  kng_item *itemBuf;  // pinned landing buffer for one launch's DPs
   bool lostWarning;
   uint32_t maxFound;
 };
