@@ -22,43 +22,53 @@
 #define TAME 0
 #define WILD 1
 
-typedef struct {
-  Int x;
-  Int d; // true distance mod n (wild offset already removed, GPUEngine.cu:672)
-  uint64_t kIdx;
-} ITEM;
+// one distinguished point as handed to the caller (reference: ITEM, GPU/GPUEngine.h:34-38)
+struct ITEM {
+  Int x;         // canonical x coordinate
+  Int d;         // TRUE distance mod n: the wild offset is already removed (GPUEngine.cu:672)
+  uint64_t kIdx; // position in the SetKangaroos arrays; kIdx & 1 = TAME / WILD
+};
 
 class GPUEngine {
 public:
+  // ---- lifetime (GPUEngine.cu:144-263): herd = nbThreadGroup * nbThreadPerGroup * 128 kangaroos ----
   GPUEngine(int nbThreadGroup, int nbThreadPerGroup, int gpuId, uint32_t maxFound);
   ~GPUEngine();
-  void SetParams(uint64_t dpMask, Int *distance, Int *px, Int *py);
+
+  // ---- walk parameters (GPUEngine.cu:140-142, :559-590) ----
+  void SetWildOffset(Int *offset); // N/2; must precede SetKangaroos
+  void SetParams(uint64_t dpMask, Int *distance, Int *px, Int *py); // 32 jumps: 128-bit distance + point
+
+  // ---- herd state (GPUEngine.cu:381-538): arrays of GetNbThread()*GetGroupSize() Ints ----
   void SetKangaroos(Int *px, Int *py, Int *d);
-  void GetKangaroos(Int *px, Int *py, Int *d);
-  void SetKangaroo(uint64_t kIdx, Int *px, Int *py, Int *d);
-  bool Launch(std::vector<ITEM> &hashFound, bool spinWait = false);
-  void SetWildOffset(Int *offset);
+  void GetKangaroos(Int *px, Int *py, Int *d);                 // waits for the in-flight launch
+  void SetKangaroo(uint64_t kIdx, Int *px, Int *py, Int *d);   // lands after the in-flight launch
+
+  // ---- the hot path (GPUEngine.cu:540-557, :592-679): one kernel = NB_RUN jumps of every kangaroo ----
+  bool callKernel();                                            // asynchronous start
+  bool callKernelAndWait();                                     // debug helper
+  bool Launch(std::vector<ITEM> &hashFound, bool spinWait = false); // DPs of the PREVIOUS kernel, then start the next
+
+  // ---- queries (GPUEngine.cu:266-308, :377-379) ----
   int GetNbThread();
-  int GetGroupSize();
-  int GetMemory();
-  bool callKernelAndWait();
-  bool callKernel();
-
+  int GetGroupSize(); // 128
+  int GetMemory();    // bytes, saturating at INT_MAX
   std::string deviceName;
+  static bool GetGridSize(int gpuId, int *x, int *y); // fills x / y when <= 0: 2*CU, 128
+  static void PrintCudaInfo();
 
+  // ---- pinned host memory (GPUEngine.cu:311-327) ----
   static void *AllocatePinnedMemory(size_t size);
   static void FreePinnedMemory(void *buff);
-  static void PrintCudaInfo();
-  static bool GetGridSize(int gpuId, int *x, int *y);
 
 private:
+  kng_engine *engine; // the whole device side lives behind the C ABI
+  kng_item *itemBuf;  // pinned landing buffer for one launch's DPs
   Int wildOffset;
   int nbThread;
   int nbThreadPerGroup;
-  kng_engine *engine; // the whole device side lives behind the C ABI
-  kng_item *itemBuf;  // pinned landing buffer for one launch's DPs
-  bool lostWarning;
   uint32_t maxFound;
+  bool lostWarning;
 };
 
 #endif
