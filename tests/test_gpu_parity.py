@@ -539,3 +539,19 @@ def test_reference_workfile_roundtrip_125bit_on_our_engine(tmp_path, orc):
     assert int(re.search(r"Count\s*:\s*(\d+)", info2).group(1)) > count1
     chk2 = subprocess.run([exe, "-wcheck", f2], capture_output=True, text=True, timeout=600).stdout
     assert "100.000% OK" in chk2, chk2[-500:]
+
+
+def test_standalone_cpp_gpuengine(tmp_path):
+    """Our C++ `class GPUEngine` + Int.h + kng_host (no reference code) through the Check.cpp protocol."""
+    import subprocess
+
+    from kangaroo_amd.build import build_all
+
+    build_all()
+    host = os.path.join(ROOT, "kangaroo_amd", "host")
+    lib = os.path.join(ROOT, "kangaroo_amd", "lib")
+    exe = str(tmp_path / "test_gpuengine")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", host, os.path.join(ROOT, "tests", "cpp", "test_gpuengine.cpp"),
+                           "-o", exe, "-L", lib, "-lkangaroo_host", "-lkangaroo_hip", "-Wl,-rpath," + lib, "-lpthread"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "CPP GPUEngine ok" in out.stdout, out.stdout[-1500:] + out.stderr[-500:]
