@@ -111,6 +111,8 @@ int kng_drain(kng_engine *h, kng_item *items, uint32_t cap, uint32_t *n_items, u
 int kng_last_kernel_ms(const kng_engine *h, float *ms);
 /* tuning knobs, must be set before kng_set_kangaroos:
  *   "group"  kangaroos walked per lane (batch size of the Montgomery inverse), power of two
+ *   "lanes"  alternatively the lane count itself (multiple of 64, need not divide the herd: waves then
+ *            walk ceil or floor of herd/lanes kangaroos)
  *   "block"  threads per workgroup (multiple of 64)
  *   "steps"  jumps per launch (default KNG_NB_RUN; only tests change it)
  *   "arith"  walk arithmetic policy: 32 = saturated 32-bit limbs with the reference's exact lazy fold

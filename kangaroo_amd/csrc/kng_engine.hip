@@ -57,7 +57,8 @@ struct WalkArgs {
     DpRecord *dp_items;
     uint32_t max_found;
     uint32_t lanes; // L
-    uint32_t group; // G
+    uint32_t group; // nominal G (exact when lanes divides the herd)
+    uint64_t n_kang; // N: lane t walks kangaroos t, t+L, ... < N, i.e. ceil((N-t)/L) of them (uniform per wave: L is a multiple of 64)
     uint32_t nsteps;
 };
 
@@ -107,8 +108,8 @@ __global__ void __launch_bounds__(256) kng_walk_kernel(const WalkArgs a) {
 
     const size_t L = a.lanes;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t G = a.group;
     if (t >= L) return;
+    const uint32_t G = (uint32_t)((a.n_kang - t + L - 1) / L);
 
     // pass 0: prefix products of dx in ascending order (GPUCompute.h:52-61 + GPUMath.h:1173-1177)
     fe acc;
@@ -533,6 +534,11 @@ int kng_set_option(kng_engine *h, const char *key, int64_t value) {
         if (value < 1 || (value & (value - 1)) || (h->n % (uint64_t)value)) return fail(KNG_E_ARG, "group must be a power of two dividing the herd");
         h->group = (uint32_t)value;
         h->lanes = (uint32_t)(h->n / h->group);
+    } else if (k == "lanes") {
+        // free choice of the lane count (multiple of 64): groups become ragged, ceil/floor(N/lanes) per wave
+        if (value < 64 || (value % 64) || (uint64_t)value > h->n) return fail(KNG_E_ARG, "lanes must be a multiple of 64 and <= herd size");
+        h->lanes = (uint32_t)value;
+        h->group = (uint32_t)((h->n + (uint64_t)value - 1) / (uint64_t)value);
     } else if (k == "block") {
         if (value < 64 || value > 256 || (value % 64)) return fail(KNG_E_ARG, "block must be 64,128,192 or 256");
         h->block = (uint32_t)value;
@@ -741,6 +747,7 @@ int kng_launch(kng_engine *h) {
     a.max_found = h->max_found;
     a.lanes = h->lanes;
     a.group = h->group;
+    a.n_kang = h->n;
     a.nsteps = h->nsteps;
     HIP_TRY(hipMemsetAsync(h->dp_count[s], 0, 4, h->walk)); // GPUEngine.cu:543
     HIP_TRY(hipEventRecord(h->ev_start[s], h->walk));
@@ -760,6 +767,7 @@ int kng_launch(kng_engine *h) {
         b.max_found = h->max_found;
         b.lanes = h->lanes;
         b.group = h->group;
+        b.n_kang = h->n;
         b.nsteps = h->nsteps;
         hipLaunchKernelGGL(kng_walk29_kernel, dim3(blocks), dim3(h->block), 0, h->walk, b);
     } else {

@@ -35,6 +35,7 @@ struct Walk29Args {
     void *dp_items; // DpRecord[]
     uint32_t max_found;
     uint32_t lanes, group, nsteps;
+    uint64_t n_kang;
 };
 
 KNG_DEV fe29 ld29(const Planes29 &p, size_t i) {
@@ -61,8 +62,8 @@ template <typename EmitFn>
 KNG_DEV void walk29_body(const Walk29Args &a, const uint32_t *tab, EmitFn emit) {
     const size_t L = a.lanes;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t G = a.group;
     if (t >= L) return;
+    const uint32_t G = (uint32_t)((a.n_kang - t + L - 1) / L);
 
     // pass 0: running products of dx in ascending order
     fe29 acc;

@@ -555,3 +555,32 @@ def test_standalone_cpp_gpuengine(tmp_path):
                            "-o", exe, "-L", lib, "-lkangaroo_host", "-lkangaroo_hip", "-Wl,-rpath," + lib, "-lpthread"])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "CPP GPUEngine ok" in out.stdout, out.stdout[-1500:] + out.stderr[-500:]
+
+
+@pytest.mark.parametrize("arith", [32, 29])
+@pytest.mark.parametrize("grid,lanes", [((3, 5), 448), ((2, 3), 320), ((4, 4), 1984)])
+def test_ragged_groups_vs_oracle(kng, orc, grid, lanes, arith):
+    """Free lane count ("lanes" option): the herd does not divide evenly, so waves walk ceil or floor
+    of N/lanes kangaroos.  Same bit-exact comparison with the oracle, two launches."""
+    n = grid[0] * grid[1] * 128
+    rp = 72
+    x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=lanes)
+    jd, jx, jy, _ = orc.jump_table(rp)
+    mask = orc.dp_mask(5)
+    eng = kng.GPUEngine(grid[0], grid[1], 0, 1 << 16, lanes=lanes, arith=arith)
+    assert eng.get_option("lanes") == lanes and n % lanes != 0
+    eng.SetParams(mask, jd, jx, jy)
+    eng.SetWildOffset(wild_offset)
+    eng.SetKangaroos(x, y, ints_to_array(true_d))
+    ox, oy = x.copy(), y.copy()
+    od = ints_to_array(device_distances(true_d, wild_offset), 2)
+    for _ in range(2):
+        eng.callKernel()
+        eng.wait()
+        got = eng.drain(raw=True)
+        want, total = orc.walk(ox, oy, od, 64, jd, jx, jy, mask, dp_cap=1 << 22)
+        key = lambda r: (int(r["kidx"]), tuple(int(v) for v in r["x"]), tuple(int(v) for v in r["d"]))  # noqa: E731
+        assert sorted(map(key, got)) == sorted(map(key, want))
+        gx, gy, gd = eng.GetKangaroos(raw=True)
+        assert np.array_equal(gx, ox) and np.array_equal(gy, oy) and np.array_equal(gd, od)
+    eng.close()
