@@ -159,7 +159,11 @@ def main():
         opts["group"] = args.group
     if args.block:
         opts["block"] = args.block
-    eng = k.GPUEngine(gx, gy, dev, 65536 * 2, **opts)  # maxFound as Kangaroo.cpp:523
+    # maxFound: the reference hard-codes 131072 (Kangaroo.cpp:523); with many GPUs the auto DP drops and a
+    # launch yields more points than that, so size the buffer for 2x the expected count instead of dropping DPs
+    expected_dps = (n * k.KNG_NB_RUN) >> dp
+    max_found = max(65536 * 2, 2 * expected_dps)
+    eng = k.GPUEngine(gx, gy, dev, max_found, **opts)
     eng.SetParams(hl.dp_mask(dp), jd, jx, jy)
     eng.SetWildOffset(woff)
     t0 = time.time()
