@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--group", type=int, default=0, help="kangaroos per lane (0 = engine default)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-herd", action="store_true", help="build the herd on the host and upload it (default: on the GPU)")
     args = ap.parse_args()
 
     # torch is plumbing here: rendezvous/barrier over RCCL and the cross-rank max of the timings
@@ -151,9 +152,6 @@ def main():
     P = 2**256 - 0x1000003D1
     _, ksx, ksy = hl.point_add((kx, ky), (sx, P - sy))
 
-    t0 = time.time()
-    x, y, d_true, woff = hl.create_herd(n, RANGE_POWER, (ksx, ksy), first_type=0, seed=ranks.herd_seed(0xBEEF))
-    t_herd = time.time() - t0
     opts = {}
     if args.group:
         opts["group"] = args.group
@@ -165,15 +163,25 @@ def main():
     max_found = max(65536 * 2, 2 * expected_dps)
     eng = k.GPUEngine(gx, gy, dev, max_found, **opts)
     eng.SetParams(hl.dp_mask(dp), jd, jx, jy)
-    eng.SetWildOffset(woff)
     t0 = time.time()
-    eng.SetKangaroos(x, y, hl.to_device_distances(d_true, woff))
-    t_up = time.time() - t0
-    del x, y, d_true
+    if args.host_herd:
+        # CreateHerd semantics on the host (batched, multi-threaded), then SetKangaroos
+        x, y, d_true, woff = hl.create_herd(n, RANGE_POWER, (ksx, ksy), first_type=0, seed=ranks.herd_seed(0xBEEF))
+        t_herd = time.time() - t0
+        eng.SetWildOffset(woff)
+        t0 = time.time()
+        eng.SetKangaroos(x, y, hl.to_device_distances(d_true, woff))
+        t_up = time.time() - t0
+        del x, y, d_true
+    else:
+        # the herd is built on the GPU (kng_build_herd): valid kangaroos d*G / K + d*G, uniform distances
+        eng.CreateHerdOnDevice(RANGE_POWER, (ksx, ksy), seed=ranks.herd_seed(0xBEEF))
+        t_herd = time.time() - t0
+        t_up = 0.0
     if rank == 0:
         log(f"{eng.deviceName}: 2^{np.log2(n):.2f} kangaroos, dp {dp}, jump avg 2^{javg:.2f}, "
             f"group {eng.get_option('group')} lanes {eng.get_option('lanes')} "
-            f"({eng.GetMemory() / 1048576.0:.1f} MB); herd built in {t_herd:.1f}s, uploaded in {t_up:.1f}s")
+            f"({eng.GetMemory() / 1048576.0:.1f} MB); herd built {'on the host' if args.host_herd else 'on the GPU'} in {t_herd * 1e3:.0f} ms, uploaded in {t_up * 1e3:.0f} ms")
 
     # warmup: W full steps
     for _ in range(args.warmup):

@@ -85,6 +85,16 @@ int kng_set_kangaroos(kng_engine *h, const uint64_t *x, size_t xs, const uint64_
  * same way through the null stream) */
 int kng_get_kangaroos(kng_engine *h, uint64_t *x, size_t xs, uint64_t *y, size_t ys, uint64_t *d,
                       size_t ds, uint64_t n);
+/* Create the whole herd ON THE DEVICE instead of uploading it (new; replaces Kangaroo::CreateHerd,
+ * Kangaroo.cpp:670-738, + SetKangaroos).  Kangaroo i gets a device distance dd uniform in
+ * [1, 2^range_power) (counter-based generator keyed by seed and i) and the point
+ *     base_type(i) + dd*G + final_add,     type(i) = i & 1,
+ * where table[w][v] = v*256^w*G for v = 1..255 (entry 0 unused), windows = ceil(range_power/8), and
+ * base_tame = b*G, base_wild = K - (N/2)*G + b*G, final_add = -b*G for a random scalar b: the random
+ * offset keeps every batched affine addition generic.  The host library computes these inputs
+ * (kngh_herd_params); points are 8 limbs: x[4], y[4].  Read the herd back with kng_get_kangaroos. */
+int kng_build_herd(kng_engine *h, int range_power, uint64_t seed, const uint64_t *table, uint32_t windows,
+                   const uint64_t base_tame[8], const uint64_t base_wild[8], const uint64_t final_add[8]);
 /* overwrite one kangaroo; stream-ordered after an in-flight launch, never blocks the host
  * (the reference issues ten blocking 8-byte copies, GPUEngine.cu:504-530) */
 int kng_set_kangaroo(kng_engine *h, uint64_t kidx, const uint64_t x[4], const uint64_t y[4],

@@ -196,6 +196,121 @@ __global__ void __launch_bounds__(256) kng_walk_kernel(const WalkArgs a) {
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// herd creation on the device (replaces Kangaroo::CreateHerd, Kangaroo.cpp:670-738,
+// followed by SetKangaroos).  Kangaroo i gets a device distance dd uniform in [1, 2^range_power) from a
+// counter-based generator and the point  B_type + dd*G - b*G  built with the SAME batched-inverse pass
+// structure as the walk: one pass per 8-bit window of dd adds table[w][byte] = byte*256^w*G (a zero byte
+// skips: dx := 1 keeps the lane's product chain intact), a last pass adds the constant -b*G.  Starting
+// from the random offset points B_tame = b*G, B_wild = K - (N/2)*G + b*G (computed by the host library)
+// keeps every addition generic (no doubling, no point at infinity).
+struct HerdArgs {
+    v16 *x01, *x23, *y01, *y23, *d, *s01, *s23;
+    const uint64_t *table; // [windows][256][8]: x limbs 0..3, y limbs 0..3 ; entry 0 of each window unused
+    uint64_t base[2][8];   // B_tame, B_wild
+    uint64_t fin[8];       // -b*G
+    uint64_t seed, n_kang;
+    uint32_t windows, range_power, lanes;
+};
+
+KNG_DEV uint64_t herd_mix(uint64_t z) { // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+KNG_DEV v16 herd_distance(uint64_t seed, uint64_t idx, uint32_t rp) {
+    uint64_t lo = herd_mix(seed + 0x9E3779B97F4A7C15ULL * (2 * idx + 1));
+    uint64_t hi = herd_mix(seed + 0x9E3779B97F4A7C15ULL * (2 * idx + 2));
+    if (rp < 64) {
+        lo &= (1ULL << rp) - 1;
+        hi = 0;
+    } else if (rp < 128) {
+        hi &= (rp == 64) ? 0 : ((1ULL << (rp - 64)) - 1);
+    }
+    if ((lo | hi) == 0) lo = 1;
+    return make_ulonglong2(lo, hi);
+}
+// addend of pass `step` for a kangaroo with distance d: table point of byte `step`, or the final constant
+KNG_DEV bool herd_addend(const HerdArgs &a, uint32_t step, const v16 &d, fe &qx, fe &qy) {
+    if (step >= a.windows) {
+        qx = fe{{a.fin[0], a.fin[1], a.fin[2], a.fin[3]}};
+        qy = fe{{a.fin[4], a.fin[5], a.fin[6], a.fin[7]}};
+        return true;
+    }
+    const uint64_t word = step < 8 ? d.x : d.y;
+    const uint32_t byte = (uint32_t)(word >> (8 * (step & 7))) & 0xFF;
+    const v16 *e = reinterpret_cast<const v16 *>(a.table + ((size_t)step * 256 + byte) * 8);
+    const v16 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+    qx = fe{{e0.x, e0.y, e1.x, e1.y}};
+    qy = fe{{e2.x, e2.y, e3.x, e3.y}};
+    return byte != 0;
+}
+
+__global__ void __launch_bounds__(256) kng_herd_kernel(const HerdArgs a) {
+    const size_t L = a.lanes;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= L) return;
+    const uint32_t G = (uint32_t)((a.n_kang - t + L - 1) / L);
+    const uint32_t nsteps = a.windows + 1;
+
+    // pass 0: distances, start points, products of the first window's dx
+    fe acc;
+    for (uint32_t g = 0; g < G; g++) {
+        const size_t idx = (size_t)g * L + t;
+        const v16 d = herd_distance(a.seed, idx, a.range_power);
+        const uint64_t *b = a.base[idx & 1];
+        const fe x{{b[0], b[1], b[2], b[3]}}, y{{b[4], b[5], b[6], b[7]}};
+        a.d[idx] = d;
+        st_fe(a.x01, a.x23, idx, x);
+        st_fe(a.y01, a.y23, idx, y);
+        fe qx, qy;
+        const bool on = herd_addend(a, 0, d, qx, qy);
+        const fe dx = on ? fe_sub(x, qx) : fe_one();
+        acc = g ? fe_mul(acc, dx) : dx;
+        st_fe(a.s01, a.s23, idx, acc);
+    }
+    for (uint32_t step = 0; step < nsteps; step++) {
+        fe inv = fe_inv(acc);
+        const bool backward = !(step & 1);
+        const bool last = (step + 1 == nsteps);
+        auto slot = [&](uint32_t k) -> size_t { return (size_t)(backward ? (G - 1 - k) : k) * L + t; };
+        for (uint32_t k = 0; k < G; k++) {
+            const size_t idx = slot(k);
+            const fe cx = ld_fe(a.x01, a.x23, idx), cy = ld_fe(a.y01, a.y23, idx);
+            const v16 d = a.d[idx];
+            fe qx, qy;
+            const bool on = herd_addend(a, step, d, qx, qy);
+            const fe dx = on ? fe_sub(cx, qx) : fe_one();
+            fe invk;
+            if (k + 1 < G) {
+                invk = fe_mul(inv, ld_fe(a.s01, a.s23, slot(k + 1)));
+                inv = fe_mul(inv, dx);
+            } else {
+                invk = inv;
+            }
+            fe rx = cx, ry = cy;
+            if (on) { // P + Q, affine (SECP256K1.cpp:238-263 formulas, operand order of GPUCompute.h:75-88)
+                const fe s = fe_mul(fe_sub(cy, qy), invk);
+                rx = fe_sub(fe_sub(fe_sqr(s), qx), cx);
+                ry = fe_sub(fe_mul(fe_sub(cx, rx), s), cy);
+                if (last) { // hand the walk canonical coordinates
+                    rx = fe_canon(rx);
+                    ry = fe_canon(ry);
+                }
+                st_fe(a.x01, a.x23, idx, rx);
+                st_fe(a.y01, a.y23, idx, ry);
+            }
+            if (!last) {
+                fe nqx, nqy;
+                const bool non = herd_addend(a, step + 1, d, nqx, nqy);
+                const fe dx2 = non ? fe_sub(rx, nqx) : fe_one();
+                acc = k ? fe_mul(acc, dx2) : dx2;
+                st_fe(a.s01, a.s23, idx, acc);
+            }
+        }
+    }
+}
+
 // overwrite one kangaroo, stream-ordered (replaces the ten 8-byte copies of GPUEngine.cu:504-530)
 __global__ void kng_patch_kernel(v16 *x01, v16 *x23, v16 *y01, v16 *y23, v16 *d, uint64_t idx, fe x,
                                  fe y, v16 dd) {
@@ -705,6 +820,39 @@ int kng_get_kangaroos(kng_engine *h, uint64_t *x, size_t xs, uint64_t *y, size_t
             }
         }
     }
+    return KNG_OK;
+}
+
+int kng_build_herd(kng_engine *h, int range_power, uint64_t seed, const uint64_t *table, uint32_t windows,
+                   const uint64_t base_tame[8], const uint64_t base_wild[8], const uint64_t final_add[8]) {
+    if (!h || !table || !base_tame || !base_wild || !final_add) return fail(KNG_E_ARG, "null argument");
+    if (range_power < 1 || range_power > 128) return fail(KNG_E_ARG, "range_power must be 1..128");
+    if (windows != (uint32_t)(range_power + 7) / 8) return fail(KNG_E_ARG, "windows must be ceil(range_power/8)");
+    if (h->arith != 32) return fail(KNG_E_STATE, "device herd creation needs walk policy arith=32");
+    if (h->outstanding) return fail(KNG_E_STATE, "a launch is outstanding");
+    HIP_TRY(hipSetDevice(h->dev));
+    uint64_t *dtab = nullptr;
+    const size_t tbytes = (size_t)windows * 256 * 8 * sizeof(uint64_t);
+    HIP_TRY(hipMalloc((void **)&dtab, tbytes));
+    HIP_TRY(hipMemcpyAsync(dtab, table, tbytes, hipMemcpyHostToDevice, h->walk));
+    HerdArgs a;
+    a.x01 = plane(h, 0); a.x23 = plane(h, 1); a.y01 = plane(h, 2); a.y23 = plane(h, 3);
+    a.d = plane(h, 4); a.s01 = plane(h, 5); a.s23 = plane(h, 6);
+    a.table = dtab;
+    memcpy(a.base[0], base_tame, 64);
+    memcpy(a.base[1], base_wild, 64);
+    memcpy(a.fin, final_add, 64);
+    a.seed = seed;
+    a.n_kang = h->n;
+    a.windows = windows;
+    a.range_power = (uint32_t)range_power;
+    a.lanes = h->lanes;
+    const uint32_t blocks = (h->lanes + h->block - 1) / h->block;
+    hipLaunchKernelGGL(kng_herd_kernel, dim3(blocks), dim3(h->block), 0, h->walk, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->walk));
+    (void)hipFree(dtab);
+    h->have_herd = true;
     return KNG_OK;
 }
 

@@ -62,6 +62,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.kng_set_kangaroos.argtypes = [C.c_void_p, _U64P, C.c_size_t, _U64P, C.c_size_t, _U64P, C.c_size_t, C.c_uint64]
     L.kng_get_kangaroos.argtypes = [C.c_void_p, _U64P, C.c_size_t, _U64P, C.c_size_t, _U64P, C.c_size_t, C.c_uint64]
     L.kng_set_kangaroo.argtypes = [C.c_void_p, C.c_uint64, _U64P, _U64P, _U64P]
+    L.kng_build_herd.argtypes = [C.c_void_p, C.c_int, C.c_uint64, _U64P, C.c_uint32, _U64P, _U64P, _U64P]
+    L.kng_build_herd.restype = C.c_int
     L.kng_launch.argtypes = [C.c_void_p]
     L.kng_wait.argtypes = [C.c_void_p, C.c_int]
     L.kng_drain.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -233,6 +235,16 @@ class GPUEngine:
         dd = np.zeros((n, 2), dtype=np.uint64)
         _check(self._L.kng_get_kangaroos(self._h, px, 4, py, 4, dd, 2, n))
         return px, py, (dd if raw else self._to_true_d(dd))
+
+    def CreateHerdOnDevice(self, range_power: int, key_xy=None, seed: int = 1) -> int:
+        """Build the whole herd on the GPU (kng_build_herd; replaces Kangaroo::CreateHerd + SetKangaroos).
+        Sets and returns the wild offset (N/2).  key_xy: the (shifted) public key for the wild herd."""
+        from . import hostlib
+
+        table, windows, bt, bw, fin, woff = hostlib.herd_params(range_power, key_xy, seed)
+        _check(self._L.kng_build_herd(self._h, range_power, seed & _M64, table, windows, bt, bw, fin))
+        self.wildOffset = woff
+        return woff
 
     def SetKangaroo(self, kIdx: int, px: int, py: int, d: int) -> None:
         if kIdx & 1:

@@ -446,6 +446,42 @@ int kngh_create_herd(uint64_t n, int range_power, const uint64_t wild_offset[4],
     return 0;
 }
 
+int kngh_herd_params(int range_power, const uint64_t wild_offset[4], const uint64_t kx[4], const uint64_t ky[4],
+                     uint64_t seed, uint64_t *table, uint64_t base_tame[8], uint64_t base_wild[8],
+                     uint64_t final_add[8]) {
+    if (range_power < 1 || range_power > 128 || !table || !base_tame || !base_wild || !final_add) return -1;
+    std::call_once(gtab_once, gtab_build);
+    const int windows = (range_power + 7) / 8;
+    memset(table, 0, (size_t)windows * 256 * 8 * sizeof(uint64_t));
+    for (int w = 0; w < windows; w++)
+        for (unsigned v = 1; v < 256; v++) {
+            const Pt &p = gt(w, v);
+            store(table + ((size_t)w * 256 + v) * 8, p.x);
+            store(table + ((size_t)w * 256 + v) * 8 + 4, p.y);
+        }
+    // b: 127 random bits (never 0), far above any distance so b + dd never wraps or hits 0 mod n
+    Xo rng(seed ^ 0x5851F42D4C957F2DULL);
+    Fe b = {{rng.next() | 1, rng.next() >> 1, 0, 0}};
+    Pt bg = scalar_mul_g(b, PINF);
+    Pt wild = PINF;
+    if (kx && ky) {
+        Pt K = {f_canon(load(kx)), f_canon(load(ky)), false};
+        Pt off = scalar_mul_g(load(wild_offset), PINF);
+        if (!off.inf) off.y = f_sub(Fe{{0, 0, 0, 0}}, off.y);
+        wild = pt_add(pt_add(K, off), bg);
+    } else {
+        wild = bg;
+    }
+    if (wild.inf || bg.inf) return -1;
+    store(base_tame, bg.x);
+    store(base_tame + 4, bg.y);
+    store(base_wild, wild.x);
+    store(base_wild + 4, wild.y);
+    store(final_add, bg.x);
+    store(final_add + 4, f_sub(Fe{{0, 0, 0, 0}}, bg.y));
+    return 0;
+}
+
 int kngh_to_device_distances(const uint64_t *d_true, uint64_t n, const uint64_t wild_offset[4], uint64_t *d_dev) {
     const Fe woff = load(wild_offset);
     for (uint64_t i = 0; i < n; i++) {

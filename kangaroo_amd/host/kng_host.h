@@ -52,6 +52,14 @@ int kngh_create_herd(uint64_t n, int range_power, const uint64_t wild_offset[4],
                      const uint64_t ky[4], int first_type, uint64_t seed, int nthreads, uint64_t *x, uint64_t *y,
                      uint64_t *d_true);
 
+/* Inputs of kng_build_herd (device-side herd creation, include/kangaroo_hip.h): the window table
+ * table[w][v] = v*256^w*G (windows = ceil(range_power/8), 256 entries of x[4],y[4] each, entry 0 zero),
+ * and the offset points base_tame = b*G, base_wild = K - wild_offset*G + b*G, final_add = -b*G for a
+ * scalar b derived from seed.  table must hold windows*256*8 uint64.  kx/ky may be NULL (tame only). */
+int kngh_herd_params(int range_power, const uint64_t wild_offset[4], const uint64_t kx[4], const uint64_t ky[4],
+                     uint64_t seed, uint64_t *table, uint64_t base_tame[8], uint64_t base_wild[8],
+                     uint64_t final_add[8]);
+
 /* (n x 4 true distances mod n) <-> (n x 2 device distances): odd indices carry +wild_offset mod n.
  * Returns 0, or -1 when a device distance does not fit 128 bits. */
 int kngh_to_device_distances(const uint64_t *d_true, uint64_t n, const uint64_t wild_offset[4], uint64_t *d_dev);

@@ -47,6 +47,7 @@ def load() -> C.CDLL:
         L.kngh_suggest_dp.argtypes = [C.c_int, C.c_double]
         L.kngh_create_herd.argtypes = [C.c_uint64, C.c_int, _U64P, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int,
                                        _U64P, _U64P, _U64P]
+        L.kngh_herd_params.argtypes = [C.c_int, _U64P, C.c_void_p, C.c_void_p, C.c_uint64, _U64P, _U64P, _U64P, _U64P]
         L.kngh_to_device_distances.argtypes = [_U64P, C.c_uint64, _U64P, _U64P]
         L.kngh_to_true_distances.argtypes = [_U64P, C.c_void_p, C.c_uint64, _U64P, _U64P]
         L.kngh_to_true_distances.restype = None
@@ -103,6 +104,22 @@ def create_herd(n: int, range_power: int, key_xy=None, first_type: int = 0, seed
     if rc != 0:
         raise RuntimeError("kngh_create_herd failed")
     return x, y, d, wild_offset
+
+
+def herd_params(range_power: int, key_xy=None, seed: int = 1):
+    """Inputs of GPUEngine.CreateHerdOnDevice / kng_build_herd: (table, windows, base_tame, base_wild, final_add, wild_offset)."""
+    wild_offset = ((1 << range_power) - 1) >> 1
+    windows = (range_power + 7) // 8
+    table = np.zeros(windows * 256 * 8, np.uint64)
+    bt, bw, fin = np.zeros(8, np.uint64), np.zeros(8, np.uint64), np.zeros(8, np.uint64)
+    if key_xy is None:
+        kx = ky = None
+    else:
+        kxa, kya = limbs(key_xy[0]), limbs(key_xy[1])
+        kx, ky = kxa.ctypes.data, kya.ctypes.data
+    if load().kngh_herd_params(range_power, limbs(wild_offset), kx, ky, seed & _M64, table, bt, bw, fin) != 0:
+        raise RuntimeError("kngh_herd_params failed")
+    return table, windows, bt, bw, fin, wild_offset
 
 
 def to_device_distances(d_true: np.ndarray, wild_offset: int) -> np.ndarray:

@@ -584,3 +584,47 @@ def test_ragged_groups_vs_oracle(kng, orc, grid, lanes, arith):
         gx, gy, gd = eng.GetKangaroos(raw=True)
         assert np.array_equal(gx, ox) and np.array_equal(gy, oy) and np.array_equal(gd, od)
     eng.close()
+
+
+@pytest.mark.parametrize("rp,grid,group", [(72, (2, 2), 16), (125, (2, 3), 64), (20, (1, 2), 1), (64, (4, 4), 128)])
+def test_device_herd_creation(kng, orc, rp, grid, group):
+    """the herd is built on the GPU (kng_build_herd).  Every kangaroo must sit at
+    d*G (tame) / K + d*G (wild) for the distance the engine reports, distances must be in range and
+    well spread, and the herd must walk exactly like an uploaded one (bit-exact against the oracle)."""
+    import kangaroo_amd.hostlib as hl
+
+    n = grid[0] * grid[1] * 128
+    key = (0xC0FFEE << 40) | 0x777
+    _, kx, ky = orc.pubkey(key)
+    jd, jx, jy, _ = orc.jump_table(rp)
+    mask = orc.dp_mask(4)
+    with kng.GPUEngine(grid[0], grid[1], 0, 1 << 16, group=group) as eng:
+        woff = eng.CreateHerdOnDevice(rp, (kx, ky), seed=99)
+        assert woff == ((1 << rp) - 1) >> 1
+        eng.SetParams(mask, jd, jx, jy)
+        px, py, d_true = eng.GetKangaroos()
+        _, _, d_dev = eng.GetKangaroos(raw=True)
+        dv = array_to_ints(d_dev)
+        assert all(1 <= v < (1 << rp) for v in dv)
+        assert len(set(dv)) > 0.99 * min(n, 1 << (rp - 1))          # no stuck generator
+        if rp >= 32:
+            assert abs(sum(v >> (rp - 8) for v in dv) / n - 127.5) < 12  # top byte roughly uniform
+        ox, oy = orc.create_herd(d_true, 0, kx, ky)                  # tame d*G / wild K + d*G
+        assert np.array_equal(ox, px) and np.array_equal(oy, py)
+        # and it walks like any other herd
+        eng.callKernel()
+        eng.wait()
+        got = eng.drain(raw=True)
+        gx, gy, gd = eng.GetKangaroos(raw=True)
+    wx, wy, wd = px.copy(), py.copy(), d_dev.copy()
+    want, total = orc.walk(wx, wy, wd, 64, jd, jx, jy, mask, dp_cap=1 << 22)
+    assert np.array_equal(gx, wx) and np.array_equal(gy, wy) and np.array_equal(gd, wd)
+    key_ = lambda r: (int(r["kidx"]), tuple(int(v) for v in r["x"]), tuple(int(v) for v in r["d"]))  # noqa: E731
+    assert sorted(map(key_, got)) == sorted(map(key_, want))
+    # a different seed gives a different herd, the same seed the same herd
+    with kng.GPUEngine(grid[0], grid[1], 0, 16, group=group) as e2:
+        e2.CreateHerdOnDevice(rp, (kx, ky), seed=99)
+        a = e2.GetKangaroos(raw=True)
+        e2.CreateHerdOnDevice(rp, (kx, ky), seed=100)
+        b = e2.GetKangaroos(raw=True)
+    assert np.array_equal(a[0], px) and not np.array_equal(b[2], d_dev)
