@@ -55,16 +55,46 @@ KNG_DEV int32_t divsteps30(int32_t zeta, uint32_t f, uint32_t g, int32_t &tu, in
     return zeta;
 }
 
+// Signed 32x32+64 multiply-accumulate chains of the matrix application.  From C++ hipcc builds each
+// int64 product out of v_mad_u64_u32 + v_mul_lo_u32 sign corrections (186 multiply-class
+// instructions per round for 90 products); v_mad_i64_i32 does it in one.  Two accumulators are
+// interleaved per statement; vcc only receives the (unused) carry-out.
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define KNG_FG_STEP(cf, cg, u, v, q, r, fi, gi)                                                            \
+    asm("v_mad_i64_i32 %0, vcc, %2, %6, %0\n\tv_mad_i64_i32 %1, vcc, %4, %6, %1\n\t"                         \
+        "v_mad_i64_i32 %0, vcc, %3, %7, %0\n\tv_mad_i64_i32 %1, vcc, %5, %7, %1"                             \
+        : "+v"(cf), "+v"(cg)                                                                               \
+        : "v"(u), "v"(v), "v"(q), "v"(r), "v"(fi), "v"(gi)                                                 \
+        : "vcc")
+#define KNG_DE_STEP(cd, ce, u, v, q, r, di, ei, md, me, pi)                                                \
+    asm("v_mad_i64_i32 %0, vcc, %2, %6, %0\n\tv_mad_i64_i32 %1, vcc, %4, %6, %1\n\t"                         \
+        "v_mad_i64_i32 %0, vcc, %3, %7, %0\n\tv_mad_i64_i32 %1, vcc, %5, %7, %1\n\t"                         \
+        "v_mad_i64_i32 %0, vcc, %8, %10, %0\n\tv_mad_i64_i32 %1, vcc, %9, %10, %1"                            \
+        : "+v"(cd), "+v"(ce)                                                                               \
+        : "v"(u), "v"(v), "v"(q), "v"(r), "v"(di), "v"(ei), "v"(md), "v"(me), "v"(pi)                      \
+        : "vcc")
+#else
+#define KNG_FG_STEP(cf, cg, u, v, q, r, fi, gi)                                                            \
+    do {                                                                                                   \
+        cf += (int64_t)(u) * (fi) + (int64_t)(v) * (gi);                                                   \
+        cg += (int64_t)(q) * (fi) + (int64_t)(r) * (gi);                                                   \
+    } while (0)
+#define KNG_DE_STEP(cd, ce, u, v, q, r, di, ei, md, me, pi)                                                \
+    do {                                                                                                   \
+        cd += (int64_t)(u) * (di) + (int64_t)(v) * (ei) + (int64_t)(pi) * (md);                            \
+        ce += (int64_t)(q) * (di) + (int64_t)(r) * (ei) + (int64_t)(pi) * (me);                            \
+    } while (0)
+#endif
+
 // (f, g) <- t * (f, g) / 2^30   (exact)
 KNG_DEV void update_fg30(int32_t f[9], int32_t g[9], int32_t u, int32_t v, int32_t q, int32_t r) {
-    int64_t cf = (int64_t)u * f[0] + (int64_t)v * g[0];
-    int64_t cg = (int64_t)q * f[0] + (int64_t)r * g[0];
+    int64_t cf = 0, cg = 0;
+    KNG_FG_STEP(cf, cg, u, v, q, r, f[0], g[0]);
     cf >>= 30;
     cg >>= 30;
 #pragma unroll
     for (int i = 1; i < 9; i++) {
-        cf += (int64_t)u * f[i] + (int64_t)v * g[i];
-        cg += (int64_t)q * f[i] + (int64_t)r * g[i];
+        KNG_FG_STEP(cf, cg, u, v, q, r, f[i], g[i]);
         f[i - 1] = (int32_t)cf & M30;
         g[i - 1] = (int32_t)cg & M30;
         cf >>= 30;
@@ -75,7 +105,8 @@ KNG_DEV void update_fg30(int32_t f[9], int32_t g[9], int32_t u, int32_t v, int32
 }
 
 // (d, e) <- t * (d, e) / 2^30 mod p, keeping both in (-2p, p)
-KNG_DEV void update_de30(int32_t d[9], int32_t e[9], int32_t u, int32_t v, int32_t q, int32_t r) {
+KNG_DEV void update_de30(int32_t d[9], int32_t e[9], int32_t u, int32_t v, int32_t q, int32_t r, int32_t pc0,
+                         int32_t pc1, int32_t pcm, int32_t pc8) {
     const int32_t sd = d[8] >> 31, se = e[8] >> 31; // sign masks
     // multiples of p that bring negative inputs back up ...
     int32_t md = (u & sd) + (v & se);
@@ -91,13 +122,14 @@ KNG_DEV void update_de30(int32_t d[9], int32_t e[9], int32_t u, int32_t v, int32
     ce >>= 30;
 #pragma unroll
     for (int i = 1; i < 9; i++) {
-        cd += (int64_t)u * d[i] + (int64_t)v * e[i] + (int64_t)p30(i) * md;
-        ce += (int64_t)q * d[i] + (int64_t)r * e[i] + (int64_t)p30(i) * me;
+        const int32_t pi = i == 1 ? pc1 : i == 8 ? pc8 : pcm;
+        KNG_DE_STEP(cd, ce, u, v, q, r, d[i], e[i], md, me, pi);
         d[i - 1] = (int32_t)cd & M30;
         e[i - 1] = (int32_t)ce & M30;
         cd >>= 30;
         ce >>= 30;
     }
+    (void)pc0;
     d[8] = (int32_t)cd;
     e[8] = (int32_t)ce;
 }
@@ -123,6 +155,13 @@ KNG_DEV_NOINLINE fe fe_inv(const fe &a_in) {
     g[7] = (int32_t)((a.v[3] >> 18) & M30);
     g[8] = (int32_t)(a.v[3] >> 48);
 
+    // the limbs of p as register operands of the asm MAD chains (an inline-asm "v" operand cannot be a literal)
+    int32_t pc0 = P30_0, pc1 = P30_1, pcm = P30_MID, pc8 = P30_8;
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(pc1));
+    asm("" : "+v"(pcm));
+    asm("" : "+v"(pc8));
+#endif
     int32_t zeta = -1;
 #pragma unroll 1
     for (int it = 0; it < 20; it++) { // 600 >= 590 division steps suffice for 256-bit inputs
@@ -130,7 +169,7 @@ KNG_DEV_NOINLINE fe fe_inv(const fe &a_in) {
         const uint32_t f0 = (uint32_t)f[0] | ((uint32_t)f[1] << 30);
         const uint32_t g0 = (uint32_t)g[0] | ((uint32_t)g[1] << 30);
         zeta = divsteps30(zeta, f0, g0, u, v, q, r);
-        update_de30(d, e, u, v, q, r);
+        update_de30(d, e, u, v, q, r, pc0, pc1, pcm, pc8);
         update_fg30(f, g, u, v, q, r);
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
         // g == 0 is a fixed point (f stays +-1, d stays the answer): leave as soon as EVERY lane of

@@ -41,7 +41,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or _LIB_PATH
+    path = path or os.environ.get("KNG_LIB_PATH") or _LIB_PATH  # KNG_LIB_PATH: A/B runs of two builds of the engine
     if not os.path.exists(path):
         raise EngineError(f"{path} is missing: run `python -m kangaroo_amd.build` (hipcc, gfx950) first")
     L = C.CDLL(path)
