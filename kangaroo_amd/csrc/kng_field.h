@@ -22,6 +22,13 @@
 #define KNG_DEV static inline
 #define KNG_DEV_NOINLINE static
 #endif
+// marks a block that is exact but (nearly) never executed: the volatile asm keeps hipcc from
+// if-converting the branch back into straight-line selects
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define KNG_RARE_PATH() asm volatile("; rare path")
+#else
+#define KNG_RARE_PATH() ((void)0)
+#endif
 
 namespace kng {
 
@@ -53,10 +60,23 @@ KNG_DEV fe fe_sub(const fe &a, const fe &b) {
     }
     const unsigned m = 0u - br; // all ones on borrow
     unsigned c = 0;
+    // "x - 0 - borrow" with a literal 0 makes hipcc materialise the borrow as 0/1 (v_cndmask) and
+    // then v_sub_co it: two instructions + a hazard nop per limb.  An opaque zero in a VGPR keeps
+    // the chain on v_subb_co_u32.
+    unsigned zero = 0;
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(zero));
+#endif
     r[0] = __builtin_subc(r[0], 977u & m, 0u, &c);
     r[1] = __builtin_subc(r[1], 1u & m, c, &c);
+    // the borrow out of the low 64 bits needs (a-b) mod 2^64 < 2^32+977: about one subtraction in
+    // 2^32.  Rippling it through limbs 2..7 stays exact but sits behind a (practically never taken)
+    // branch instead of costing 6 dependent v_subb_co_u32 every time.
+    if (__builtin_expect(c != 0, 0)) {
+        KNG_RARE_PATH();
 #pragma unroll
-    for (int i = 2; i < 8; i++) r[i] = __builtin_subc(r[i], 0u, c, &c);
+        for (int i = 2; i < 8; i++) r[i] = __builtin_subc(r[i], zero, c, &c);
+    }
     return fe{{(uint64_t)r[0] | ((uint64_t)r[1] << 32), (uint64_t)r[2] | ((uint64_t)r[3] << 32),
                (uint64_t)r[4] | ((uint64_t)r[5] << 32), (uint64_t)r[6] | ((uint64_t)r[7] << 32)}};
 }
@@ -175,6 +195,10 @@ namespace kng {
 // Same fold on 32-bit words: S = lo + hi*K exactly, T = S >> 256 (<= K), r = (S mod 2^256) + T*K
 // mod 2^256 -- the integer the reference computes (last carry dropped).
 KNG_DEV fe fe_fold32(const uint32_t w[16]) {
+    unsigned zero = 0; // opaque zero: see fe_sub
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(zero));
+#endif
     uint64_t q[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) q[j] = (uint64_t)w[8 + j] * 977u + w[j]; // < 2^43
@@ -184,7 +208,7 @@ KNG_DEV fe fe_fold32(const uint32_t w[16]) {
     t[0] = (uint32_t)q[0];
 #pragma unroll
     for (int j = 1; j < 8; j++) t[j] = KNG_ADDC32((uint32_t)q[j], w[8 + j - 1], c, &c);
-    t[8] = KNG_ADDC32(0u, w[15], c, &c);
+    t[8] = KNG_ADDC32(zero, w[15], c, &c);
     uint32_t top = c;
     c = 0;
 #pragma unroll
@@ -202,7 +226,13 @@ KNG_DEV fe fe_fold32(const uint32_t w[16]) {
     r[1] = KNG_ADDC32(t[1], a1, c, &c);
     r[2] = KNG_ADDC32(t[2], a2, c, &c);
 #pragma unroll
-    for (int j = 3; j < 8; j++) r[j] = KNG_ADDC32(t[j], 0u, c, &c);
+    for (int j = 3; j < 8; j++) r[j] = t[j];
+    // a2 <= 3: the carry out of limb 2 needs t[2] >= 2^32 - 4 (see fe_sub: exact, rarely taken)
+    if (__builtin_expect(c != 0, 0)) {
+        KNG_RARE_PATH();
+#pragma unroll
+        for (int j = 3; j < 8; j++) r[j] = KNG_ADDC32(r[j], zero, c, &c);
+    }
     // final carry dropped on purpose (IntMod.cpp:944)
     return fe{{(uint64_t)r[0] | ((uint64_t)r[1] << 32), (uint64_t)r[2] | ((uint64_t)r[3] << 32),
                (uint64_t)r[4] | ((uint64_t)r[5] << 32), (uint64_t)r[6] | ((uint64_t)r[7] << 32)}};
