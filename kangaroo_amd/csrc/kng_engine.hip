@@ -101,18 +101,23 @@ KNG_DEV void emit_dp(bool is_dp, const fe &x, const v16 &d, uint64_t kidx, const
 }
 
 // The hot kernel.  Replaces comp_kangaroos/ComputeKangaroos (GPUEngine.cu:35-40, GPUCompute.h:22-117).
-__global__ void __launch_bounds__(256) kng_walk_kernel(const WalkArgs a) {
-    __shared__ uint64_t tab[JT_WORDS];
-    for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
-    __syncthreads();
-
+//
+// SHARE > 1 (256*SHARE-thread blocks, option "share"): the SHARE waves that occupy one SIMD (waves w, w+4,
+// .. of the block) share ONE inversion per jump.  Waves w+4.. park their lane products in LDS and wait at
+// the barrier; wave w inverts the product of all chains and hands the individual inverses back, e.g.
+//     i = 1/(acc*pb) ;  1/acc = i*pb ;  1/pb = i*acc          (3 extra multiplications per lane pair)
+// Two co-resident waves inverting side by side need ~2 x 64.5K SIMD cycles per jump of the pair; one wave
+// alone on the SIMD needs ~72K.  Results are unchanged (the canonical residue is the same).
+template <int SHARE>
+KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
     const size_t L = a.lanes;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= L) return;
-    const uint32_t G = (uint32_t)((a.n_kang - t + L - 1) / L);
+    if (SHARE == 1 && t >= L) return;
+    // SHARE: every thread reaches the barriers; lanes beyond L walk nothing (wave-uniform: L % 64 == 0)
+    const uint32_t G = t < L ? (uint32_t)((a.n_kang - t + L - 1) / L) : 0;
 
     // pass 0: prefix products of dx in ascending order (GPUCompute.h:52-61 + GPUMath.h:1173-1177)
-    fe acc;
+    fe acc = fe_one();
     for (uint32_t g = 0; g < G; g++) {
         const size_t idx = (size_t)g * L + t;
         const fe x = ld_fe(a.x01, a.x23, idx);
@@ -124,7 +129,43 @@ __global__ void __launch_bounds__(256) kng_walk_kernel(const WalkArgs a) {
 
     for (uint32_t step = 0; step < a.nsteps; step++) {
         // one inversion per lane per jump of the whole group (GPUMath.h:1179-1180)
-        fe inv = fe_inv(acc);
+        fe inv;
+        if (SHARE > 1) {
+            // chains 0..SHARE-1 of this lane pair-up: chain c is thread pair + 256*c
+            const uint32_t pair = threadIdx.x & 255, chain = threadIdx.x >> 8;
+            if (chain) {
+                xch[(2 * chain - 2) * 256 + pair] = make_ulonglong2(acc.v[0], acc.v[1]);
+                xch[(2 * chain - 1) * 256 + pair] = make_ulonglong2(acc.v[2], acc.v[3]);
+            }
+            __syncthreads();
+            if (!chain) {
+                fe pb[SHARE], pre[SHARE]; // partner products, prefix products acc*pb[1]*..*pb[c]
+                pre[0] = acc;
+#pragma unroll
+                for (int c = 1; c < SHARE; c++) {
+                    const v16 b0 = xch[(2 * c - 2) * 256 + pair], b1 = xch[(2 * c - 1) * 256 + pair];
+                    pb[c] = fe{{b0.x, b0.y, b1.x, b1.y}};
+                    pre[c] = fe_mul(pre[c - 1], pb[c]);
+                }
+                fe i = fe_inv(pre[SHARE - 1]);
+#pragma unroll
+                for (int c = SHARE - 1; c >= 1; c--) {
+                    const fe ib = fe_mul(i, pre[c - 1]); // 1/pb[c]
+                    i = fe_mul(i, pb[c]);                // 1/pre[c-1]
+                    xch[(2 * c - 2) * 256 + pair] = make_ulonglong2(ib.v[0], ib.v[1]);
+                    xch[(2 * c - 1) * 256 + pair] = make_ulonglong2(ib.v[2], ib.v[3]);
+                }
+                inv = i;
+            }
+            __syncthreads();
+            if (chain) {
+                const v16 b0 = xch[(2 * chain - 2) * 256 + pair], b1 = xch[(2 * chain - 1) * 256 + pair];
+                inv = fe{{b0.x, b0.y, b1.x, b1.y}};
+            }
+            if (G == 0) continue;
+        } else {
+            inv = fe_inv(acc);
+        }
         const bool backward = !(step & 1); // reverse of the pass that produced the products
         const bool last = (step + 1 == a.nsteps);
         // slot(k): kangaroo processed k-th in this pass
@@ -194,6 +235,22 @@ __global__ void __launch_bounds__(256) kng_walk_kernel(const WalkArgs a) {
             idx = nidx;
         }
     }
+}
+
+__global__ void __launch_bounds__(256) kng_walk_kernel(const WalkArgs a) {
+    __shared__ uint64_t tab[JT_WORDS];
+    for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
+    __syncthreads();
+    walk_body<1>(a, tab, nullptr);
+}
+
+template <int SHARE>
+__global__ void __launch_bounds__(256 * SHARE) kng_walk_share_kernel(const WalkArgs a) {
+    __shared__ uint64_t tab[JT_WORDS];
+    __shared__ v16 xch[512 * (SHARE - 1)];
+    for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
+    __syncthreads();
+    walk_body<SHARE>(a, tab, xch);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -421,6 +478,7 @@ struct kng_engine {
     uint32_t lanes = 0;
     int cu_count = 0;
     // device memory
+    int share = 2;         // waves per SIMD (w, w+4, ..) of one 256*share-thread block that share one inversion per jump (policy 32)
     int arith = 32;        // walk policy: 32 = reference-exact lazy fold on saturated limbs, 29 = carry-free 9x29
     v16 *planes = nullptr; // 7 planes of n v16, then (policy 29) 3 planes of n dwords
     uint32_t *jtab29 = nullptr;
@@ -664,6 +722,9 @@ int kng_set_option(kng_engine *h, const char *key, int64_t value) {
     } else if (k == "steps") {
         if (value < 1 || value > 1 << 20) return fail(KNG_E_ARG, "steps out of range");
         h->nsteps = (uint32_t)value;
+    } else if (k == "share") {
+        if (value < 1 || value > 3) return fail(KNG_E_ARG, "share must be 1, 2 or 3");
+        h->share = (int)value;
     } else {
         return fail(KNG_E_ARG, "unknown option '%s'", key);
     }
@@ -678,6 +739,7 @@ int kng_get_option(const kng_engine *h, const char *key, int64_t *value) {
     else if (k == "steps") *value = h->nsteps;
     else if (k == "arith") *value = h->arith;
     else if (k == "lanes") *value = h->lanes;
+    else if (k == "share") *value = h->share;
     else if (k == "cu_count") *value = h->cu_count;
     else if (k == "waves_per_cu") *value = h->cu_count ? (int64_t)((h->lanes / 64 + h->cu_count - 1) / h->cu_count) : 0;
     else return fail(KNG_E_ARG, "unknown option '%s'", key);
@@ -919,7 +981,12 @@ int kng_launch(kng_engine *h) {
         b.nsteps = h->nsteps;
         hipLaunchKernelGGL(kng_walk29_kernel, dim3(blocks), dim3(h->block), 0, h->walk, b);
     } else {
-        hipLaunchKernelGGL(kng_walk_kernel, dim3(blocks), dim3(h->block), 0, h->walk, a);
+        if (h->share == 2)
+            hipLaunchKernelGGL(kng_walk_share_kernel<2>, dim3((h->lanes + 511) / 512), dim3(512), 0, h->walk, a);
+        else if (h->share == 3)
+            hipLaunchKernelGGL(kng_walk_share_kernel<3>, dim3((h->lanes + 767) / 768), dim3(768), 0, h->walk, a);
+        else
+            hipLaunchKernelGGL(kng_walk_kernel, dim3(blocks), dim3(h->block), 0, h->walk, a);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev_stop[s], h->walk));

@@ -586,6 +586,36 @@ def test_ragged_groups_vs_oracle(kng, orc, grid, lanes, arith):
     eng.close()
 
 
+@pytest.mark.parametrize("share", [2, 3])
+@pytest.mark.parametrize("grid,opt", [((4, 4), dict(group=4)), ((4, 4), dict(group=128)), ((3, 5), dict(lanes=448)),
+                                      ((2, 3), dict(lanes=320)), ((8, 4), dict(group=2))])
+def test_shared_inversion_vs_oracle(kng, orc, grid, opt, share):
+    """Option "share": waves w, w+4(, w+8) of a 512/768-thread block invert the product of their lane chains once.
+    Covers full blocks, a partner wave without work (lanes % 512 != 0) and ragged groups; three launches."""
+    n = grid[0] * grid[1] * 128
+    rp = 72
+    x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=n + 7)
+    jd, jx, jy, _ = orc.jump_table(rp)
+    mask = orc.dp_mask(5)
+    eng = kng.GPUEngine(grid[0], grid[1], 0, 1 << 16, share=share, **opt)
+    assert eng.get_option("share") == share
+    eng.SetParams(mask, jd, jx, jy)
+    eng.SetWildOffset(wild_offset)
+    eng.SetKangaroos(x, y, ints_to_array(true_d))
+    ox, oy = x.copy(), y.copy()
+    od = ints_to_array(device_distances(true_d, wild_offset), 2)
+    for _ in range(3):
+        eng.callKernel()
+        eng.wait()
+        got = eng.drain(raw=True)
+        want, total = orc.walk(ox, oy, od, 64, jd, jx, jy, mask, dp_cap=1 << 22)
+        key = lambda r: (int(r["kidx"]), tuple(int(v) for v in r["x"]), tuple(int(v) for v in r["d"]))  # noqa: E731
+        assert sorted(map(key, got)) == sorted(map(key, want))
+        gx, gy, gd = eng.GetKangaroos(raw=True)
+        assert np.array_equal(gx, ox) and np.array_equal(gy, oy) and np.array_equal(gd, od)
+    eng.close()
+
+
 @pytest.mark.parametrize("rp,grid,group", [(72, (2, 2), 16), (125, (2, 3), 64), (20, (1, 2), 1), (64, (4, 4), 128)])
 def test_device_herd_creation(kng, orc, rp, grid, group):
     """the herd is built on the GPU (kng_build_herd).  Every kangaroo must sit at
