@@ -239,14 +239,16 @@ def main():
             "workload": f"80-bit range single key, auto DP {dp}, herd {gx}x{gy}x128 = 2^{np.log2(n):.0f} kangaroos/GPU, "
                         f"{k.KNG_NB_RUN} jumps/launch",
             "range_power": RANGE_POWER, "dp": dp, "grid": [gx, gy], "kangaroos_per_gpu": n,
-            "group": eng.get_option("group"), "lanes": eng.get_option("lanes"), "device": info["name"], "arch": info["arch"],
+            "group": eng.get_option("group"), "lanes": eng.get_option("lanes"), "share": eng.get_option("share"), "device": info["name"], "arch": info["arch"],
             "parallelism": f"independent herds x{n_gpus}, no collective",
             "dps_per_step": round(dps / args.steps, 1), "dps_lost": lost,
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "kng_walk_kernel", "kernel_ms": round(kms, 3),
+            "kernel": {1: "kng_walk_kernel", 2: "kng_walk_share_kernel<2>", 3: "kng_walk_share_kernel<3>"}[eng.get_option("share")]
+            if eng.get_option("arith") == 32 else "kng_walk29_kernel",
+            "kernel_ms": round(kms, 3),
             "alg_bytes_per_launch": jumps_per_step * ALG_BYTES_PER_JUMP,
         },
     }

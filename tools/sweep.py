@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--launches", type=int, default=3)
     ap.add_argument("--dp", type=int, default=14)
     ap.add_argument("--ariths", default="29,32")
-    ap.add_argument("--shares", default="1", help="comma list of 1/2/3: waves per SIMD sharing one inversion")
+    ap.add_argument("--shares", default="2", help="comma list of 1/2/3: waves per SIMD sharing one inversion")
     ap.add_argument("--lanes", default="", help="explicit lane counts (ragged groups); overrides --groups")
     a = ap.parse_args()
     gx, gy = (int(v) for v in a.grid.split(","))
