@@ -85,6 +85,15 @@ int kng_set_kangaroos(kng_engine *h, const uint64_t *x, size_t xs, const uint64_
  * same way through the null stream) */
 int kng_get_kangaroos(kng_engine *h, uint64_t *x, size_t xs, uint64_t *y, size_t ys, uint64_t *d,
                       size_t ds, uint64_t n);
+/* The same for kangaroos first .. first+count-1 only (x, y, d address kangaroo `first` at index 0): lets a
+ * caller stream a herd to or from a work file (Backup.cpp:525-546 / :211-231, 96 B per kangaroo) in chunks
+ * through the engine's pinned staging buffer instead of holding 80 B x herd in host memory.  The herd counts
+ * as loaded once a range ending at the last kangaroo has been set.  Copies are stream-ordered behind an
+ * in-flight launch, like the whole-herd calls. */
+int kng_set_kangaroos_range(kng_engine *h, uint64_t first, uint64_t count, const uint64_t *x, size_t xs,
+                            const uint64_t *y, size_t ys, const uint64_t *d, size_t ds);
+int kng_get_kangaroos_range(kng_engine *h, uint64_t first, uint64_t count, uint64_t *x, size_t xs, uint64_t *y,
+                            size_t ys, uint64_t *d, size_t ds);
 /* Create the whole herd ON THE DEVICE instead of uploading it (new; replaces Kangaroo::CreateHerd,
  * Kangaroo.cpp:670-738, + SetKangaroos).  Kangaroo i gets a device distance dd uniform in
  * [1, 2^range_power) (counter-based generator keyed by seed and i) and the point
@@ -124,6 +133,8 @@ int kng_last_kernel_ms(const kng_engine *h, float *ms);
  *   "lanes"  alternatively the lane count itself (multiple of 64, need not divide the herd: waves then
  *            walk ceil or floor of herd/lanes kangaroos)
  *   "block"  threads per workgroup (multiple of 64)
+ *   "share"  waves of one SIMD that share one modular inversion per jump: 1 = none (256-thread blocks),
+ *            2 (default) / 3 = waves w, w+4(, w+8) of a 512/768-thread block ("block" is then ignored)
  *   "steps"  jumps per launch (default KNG_NB_RUN; only tests change it)
  *   "arith"  walk arithmetic policy: 32 = saturated 32-bit limbs with the reference's exact lazy fold
  *            (GPUMath.h:840-856; default), 29 = carry-free 9x29-bit limbs (same speed on MI355X: fewer

@@ -796,12 +796,24 @@ int kng_set_params(kng_engine *h, uint64_t dp_mask, const uint64_t *jd, const ui
 
 int kng_set_kangaroos(kng_engine *h, const uint64_t *x, size_t xs, const uint64_t *y, size_t ys, const uint64_t *d,
                       size_t ds, uint64_t n) {
-    if (!h || !x || !y || !d) return fail(KNG_E_ARG, "null argument");
+    if (!h) return fail(KNG_E_ARG, "null argument");
     if (n != h->n) return fail(KNG_E_ARG, "expected %llu kangaroos, got %llu", (unsigned long long)h->n, (unsigned long long)n);
+    return kng_set_kangaroos_range(h, 0, n, x, xs, y, ys, d, ds);
+}
+
+int kng_set_kangaroos_range(kng_engine *h, uint64_t first, uint64_t count, const uint64_t *x, size_t xs, const uint64_t *y,
+                            size_t ys, const uint64_t *d, size_t ds) {
+    if (!h || !x || !y || !d) return fail(KNG_E_ARG, "null argument");
+    if (first > h->n || count > h->n - first) return fail(KNG_E_ARG, "range %llu+%llu outside the herd of %llu", (unsigned long long)first, (unsigned long long)count, (unsigned long long)h->n);
     if (xs < 4 || ys < 4 || ds < 2) return fail(KNG_E_ARG, "bad stride");
     HIP_TRY(hipSetDevice(h->dev));
     const size_t C = h->stage_kang;
-    for (uint64_t c0 = 0; c0 < n; c0 += C) {
+    // x, y, d address kangaroo `first` at index 0
+    x -= first * xs;
+    y -= first * ys;
+    d -= first * ds;
+    const uint64_t n = first + count;
+    for (uint64_t c0 = first; c0 < n; c0 += C) {
         const size_t m = (size_t)((n - c0 < C) ? (n - c0) : C);
         v16 *st = h->h_stage;
         if (h->arith == 29) {
@@ -839,18 +851,30 @@ int kng_set_kangaroos(kng_engine *h, const uint64_t *x, size_t xs, const uint64_
             HIP_TRY(hipMemcpyAsync(plane(h, k) + c0, st + (size_t)k * C, m * sizeof(v16), hipMemcpyHostToDevice, h->walk));
         HIP_TRY(hipStreamSynchronize(h->walk)); // staging buffer is reused
     }
-    h->have_herd = true;
+    // the herd counts as loaded once its last kangaroo has been written (ranges are normally uploaded in order)
+    if (n == h->n) h->have_herd = true;
     return KNG_OK;
 }
 
 int kng_get_kangaroos(kng_engine *h, uint64_t *x, size_t xs, uint64_t *y, size_t ys, uint64_t *d, size_t ds, uint64_t n) {
-    if (!h || !x || !y || !d) return fail(KNG_E_ARG, "null argument");
+    if (!h) return fail(KNG_E_ARG, "null argument");
     if (n != h->n) return fail(KNG_E_ARG, "expected %llu kangaroos, got %llu", (unsigned long long)h->n, (unsigned long long)n);
+    return kng_get_kangaroos_range(h, 0, n, x, xs, y, ys, d, ds);
+}
+
+int kng_get_kangaroos_range(kng_engine *h, uint64_t first, uint64_t count, uint64_t *x, size_t xs, uint64_t *y, size_t ys,
+                            uint64_t *d, size_t ds) {
+    if (!h || !x || !y || !d) return fail(KNG_E_ARG, "null argument");
+    if (first > h->n || count > h->n - first) return fail(KNG_E_ARG, "range %llu+%llu outside the herd of %llu", (unsigned long long)first, (unsigned long long)count, (unsigned long long)h->n);
     if (xs < 4 || ys < 4 || ds < 2) return fail(KNG_E_ARG, "bad stride");
     if (!h->have_herd) return fail(KNG_E_STATE, "no herd loaded");
     HIP_TRY(hipSetDevice(h->dev));
     const size_t C = h->stage_kang;
-    for (uint64_t c0 = 0; c0 < n; c0 += C) {
+    x -= first * xs;
+    y -= first * ys;
+    d -= first * ds;
+    const uint64_t n = first + count;
+    for (uint64_t c0 = first; c0 < n; c0 += C) {
         const size_t m = (size_t)((n - c0 < C) ? (n - c0) : C);
         v16 *st = h->h_stage;
         // stream-ordered behind an in-flight launch: returns the state that launch leaves

@@ -1,0 +1,641 @@
+// kng_solver.cpp -- see kng_solver.h.  Product code: host pipeline over the C ABI of the engine.
+#include "kng_solver.h"
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/kangaroo_hip.h"
+#include "kng_dptable.h"
+#include "kng_host.h"
+#include "kng_workfile.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char *fmt, ...) {
+    char buf[768];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return -1;
+}
+
+using Clock = std::chrono::steady_clock;
+double seconds_since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+
+struct U256 {
+    uint64_t v[4];
+};
+bool is_zero(const uint64_t a[4]) { return (a[0] | a[1] | a[2] | a[3]) == 0; }
+bool eq4(const uint64_t a[4], const uint64_t b[4]) { return std::memcmp(a, b, 32) == 0; }
+// a - b over 256 bits (caller guarantees a >= b); shift right by one; bit length
+U256 sub256(const uint64_t a[4], const uint64_t b[4]) {
+    U256 r;
+    unsigned __int128 br = 0;
+    for (int i = 0; i < 4; i++) {
+        const unsigned __int128 t = (unsigned __int128)a[i] - b[i] - br;
+        r.v[i] = (uint64_t)t;
+        br = (t >> 64) & 1;
+    }
+    return r;
+}
+U256 shr1(const U256 &a) {
+    U256 r;
+    for (int i = 0; i < 4; i++) r.v[i] = (a.v[i] >> 1) | (i < 3 ? a.v[i + 1] << 63 : 0);
+    return r;
+}
+int bit_length(const U256 &a) {
+    for (int i = 3; i >= 0; i--)
+        if (a.v[i]) return 64 * i + 64 - __builtin_clzll(a.v[i]);
+    return 0;
+}
+const uint64_t P_FIELD[4] = {0xFFFFFFFEFFFFFC2FULL, ~0ULL, ~0ULL, ~0ULL};
+const uint64_t ZERO4[4] = {0, 0, 0, 0};
+
+// one distinguished point on its way to the table
+struct DpMsg {
+    kngt_entry e;
+    uint32_t bucket;
+    uint32_t gpu;
+    uint64_t kidx;
+};
+
+struct Consumer {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::vector<DpMsg>> q;
+    std::thread th;
+};
+
+struct Worker {
+    int index = 0, dev = 0, grid_x = 0, grid_y = 0;
+    kng_engine *eng = nullptr;
+    uint64_t n = 0;
+    std::thread th;
+    std::mutex reset_m;
+    std::vector<uint64_t> resets; // kangaroos to replace (same-herd collisions), filled by the consumers
+    std::atomic<uint64_t> launches{0};
+    double kernel_ms_sum = 0; // GPU thread only; read after pause/stop or approximately for stats
+    bool ended = false, paused = false; // guarded by kngs_solver::ctl_m
+    uint64_t reset_seq = 0;
+};
+
+} // namespace
+
+struct kngs_solver {
+    kngs_config cfg;
+    // derived (InitRange / InitSearchKey / CreateJumpTable)
+    int range_power = 0, dp = 0;
+    U256 wild_offset{};
+    uint64_t skx[4], sky[4]; // keyToSearch = key - rangeStart*G
+    uint64_t jd[32 * 2], jx[32 * 4], jy[32 * 4];
+    uint64_t dp_mask = 0;
+
+    kngt_table *table = nullptr;
+    std::vector<Worker *> workers;
+    std::vector<Consumer *> consumers;
+    std::atomic<uint64_t> inflight{0}; // DP messages queued but not yet in the table
+
+    // control
+    std::mutex ctl_m;
+    std::condition_variable ctl_cv;
+    std::atomic<bool> stop{false}, solved{false}, failed{false}, consumers_quit{false};
+    std::atomic<int> pause_req{0};
+    std::mutex save_m;
+    std::string error;
+    bool started = false, joined = false;
+    uint64_t priv[4] = {0, 0, 0, 0};
+
+    // counters
+    std::atomic<uint64_t> dps{0}, dps_lost{0}, same_herd{0}, wrong{0};
+    uint64_t offset_count = 0;
+    double offset_seconds = 0;
+    Clock::time_point t_start;
+    double run_seconds = 0; // frozen at stop
+
+    // restored herds
+    kngw_file *herd_file = nullptr;
+    uint64_t herd_left = 0;
+};
+
+namespace {
+
+void set_error(kngs_solver *s, const std::string &msg) {
+    {
+        std::lock_guard<std::mutex> g(s->ctl_m);
+        if (s->error.empty()) s->error = msg;
+    }
+    s->failed = true;
+    s->stop = true;
+    s->ctl_cv.notify_all();
+}
+
+// Kangaroo::CheckKey (Kangaroo.cpp:233-268) for the four sign combinations of (Td, Wd)
+bool resolve(kngs_solver *s, const uint64_t td[4], const uint64_t wd[4], uint64_t priv[4]) {
+    for (int type = 0; type < 4; type++) {
+        uint64_t d1[4], d2[4], pk[4], px[4], py[4];
+        if (type & 1) kngh_sub_order(ZERO4, td, d1); else std::memcpy(d1, td, 32);
+        if (type & 2) kngh_sub_order(ZERO4, wd, d2); else std::memcpy(d2, wd, 32);
+        kngh_add_order(d1, d2, pk);
+        if (kngh_pubkey(pk, px, py) != 0) continue;
+        if (!eq4(px, s->skx)) continue;
+        if (!eq4(py, s->sky)) kngh_sub_order(ZERO4, pk, pk); // P == -keyToSearch
+        kngh_add_order(pk, s->cfg.range_start, priv);
+        // Kangaroo::Output (:175-217): the answer must reproduce the public key
+        if (kngh_pubkey(priv, px, py) == 0 && eq4(px, s->cfg.key_x) && eq4(py, s->cfg.key_y)) return true;
+    }
+    return false;
+}
+
+void request_reset(kngs_solver *s, const DpMsg &m) {
+    Worker *w = s->workers[m.gpu];
+    std::lock_guard<std::mutex> g(w->reset_m);
+    w->resets.push_back(m.kidx);
+}
+
+void consumer_main(kngs_solver *s, Consumer *c) {
+    for (;;) {
+        std::vector<DpMsg> batch;
+        {
+            std::unique_lock<std::mutex> lk(c->m);
+            c->cv.wait(lk, [&] { return !c->q.empty() || s->consumers_quit.load(); });
+            if (c->q.empty()) return;
+            batch.swap(c->q.front());
+            c->q.pop_front();
+        }
+        for (const DpMsg &m : batch) {
+            if (s->solved) break;
+            kngt_entry other;
+            const int st = kngt_add_entry(s->table, m.bucket, &m.e, &other);
+            if (st == KNGT_ADD_OK) continue;
+            if (st < 0) {
+                set_error(s, "out of memory in the distinguished-point table");
+                break;
+            }
+            bool replace = true; // AddToTable() == false (Kangaroo.cpp:599-606)
+            if (st == KNGT_ADD_COLLISION) {
+                uint64_t d_new[4], d_old[4];
+                uint32_t t_new, t_old;
+                kngt_decode(m.e.d, d_new, &t_new);
+                kngt_decode(other.d, d_old, &t_old);
+                if (t_new != t_old) {
+                    uint64_t priv[4];
+                    const uint64_t *td = t_new == 0 ? d_new : d_old, *wd = t_new == 0 ? d_old : d_new;
+                    if (resolve(s, td, wd, priv)) {
+                        {
+                            std::lock_guard<std::mutex> g(s->ctl_m);
+                            std::memcpy(s->priv, priv, 32);
+                        }
+                        s->solved = true;
+                        s->stop = true;
+                        s->ctl_cv.notify_all();
+                        replace = false;
+                    } else {
+                        s->wrong++;
+                    }
+                }
+            }
+            if (replace) {
+                s->same_herd++;
+                request_reset(s, m);
+            }
+        }
+        s->inflight -= batch.size();
+    }
+}
+
+// replace kangaroo kidx of worker w by a fresh one of the same type (CreateHerd(1,..) + SetKangaroo)
+int replace_kangaroo(kngs_solver *s, Worker *w, uint64_t kidx) {
+    uint64_t x[4], y[4], d[4], dd[4];
+    const int type = (int)(kidx & 1);
+    const uint64_t seed = s->cfg.seed ^ (0x9E3779B97F4A7C15ULL * (++w->reset_seq)) ^ ((uint64_t)w->index << 56) ^ kidx;
+    if (kngh_create_herd(1, s->range_power, s->wild_offset.v, s->skx, s->sky, type, seed, 1, x, y, d) != 0)
+        return fail("kngh_create_herd failed");
+    if (type) kngh_add_order(d, s->wild_offset.v, dd); else std::memcpy(dd, d, 32);
+    if (dd[2] | dd[3]) return fail("replacement distance does not fit 128 bits");
+    if (kng_set_kangaroo(w->eng, kidx, x, y, dd) != KNG_OK) return fail("kng_set_kangaroo: %s", kng_last_error());
+    return 0;
+}
+
+void worker_main(kngs_solver *s, Worker *w) {
+    const uint32_t cap = s->cfg.max_found;
+    std::vector<kng_item> items(cap);
+    std::vector<uint64_t> ddev, kidx, dtrue;
+    const size_t nc = s->consumers.size();
+    std::vector<std::vector<DpMsg>> out(nc);
+    auto bail = [&](const std::string &msg) {
+        set_error(s, msg);
+        std::lock_guard<std::mutex> g(s->ctl_m);
+        w->ended = true;
+        s->ctl_cv.notify_all();
+    };
+
+    if (kng_launch(w->eng) != KNG_OK) return bail(std::string("kng_launch: ") + kng_last_error());
+    for (;;) {
+        if (kng_wait(w->eng, 0) != KNG_OK) return bail(std::string("kng_wait: ") + kng_last_error());
+        float ms = 0;
+        kng_last_kernel_ms(w->eng, &ms);
+        w->kernel_ms_sum += ms;
+        const uint64_t done = ++w->launches;
+        const bool last = s->cfg.max_launches && done >= s->cfg.max_launches;
+        const bool go_on = !s->stop && !s->pause_req && !last;
+        // launch k+1 first, then look at the points of launch k (DP buffers are double-buffered)
+        if (go_on && kng_launch(w->eng) != KNG_OK) return bail(std::string("kng_launch: ") + kng_last_error());
+
+        uint32_t n_items = 0, n_lost = 0;
+        if (kng_drain(w->eng, items.data(), cap, &n_items, &n_lost) != KNG_OK) return bail(std::string("kng_drain: ") + kng_last_error());
+        s->dps += n_items;
+        s->dps_lost += n_lost;
+        if (n_items) {
+            ddev.resize((size_t)n_items * 2);
+            kidx.resize(n_items);
+            dtrue.resize((size_t)n_items * 4);
+            for (uint32_t i = 0; i < n_items; i++) {
+                ddev[2 * i] = items[i].d[0];
+                ddev[2 * i + 1] = items[i].d[1];
+                kidx[i] = items[i].kidx;
+            }
+            // GPUEngine.cu:672: wild distances leave the engine with the offset still added
+            kngh_to_true_distances(ddev.data(), kidx.data(), n_items, s->wild_offset.v, dtrue.data());
+            for (uint32_t i = 0; i < n_items; i++) {
+                DpMsg m;
+                kngt_encode(items[i].x, &dtrue[4 * (size_t)i], (uint32_t)(items[i].kidx & 1), &m.bucket, &m.e);
+                m.gpu = (uint32_t)w->index;
+                m.kidx = items[i].kidx;
+                out[m.bucket % nc].push_back(m);
+            }
+            for (size_t c = 0; c < nc; c++) {
+                if (out[c].empty()) continue;
+                s->inflight += out[c].size();
+                Consumer *cs = s->consumers[c];
+                {
+                    std::lock_guard<std::mutex> g(cs->m);
+                    cs->q.emplace_back(std::move(out[c]));
+                }
+                cs->cv.notify_one();
+                out[c].clear();
+            }
+        }
+        // kangaroos the consumers asked to replace; stream-ordered behind the launch in flight
+        std::vector<uint64_t> todo;
+        {
+            std::lock_guard<std::mutex> g(w->reset_m);
+            todo.swap(w->resets);
+        }
+        for (uint64_t k : todo)
+            if (replace_kangaroo(s, w, k) != 0) return bail(g_err);
+
+        if (go_on) continue;
+        // ---- launch boundary without a kernel in flight: park for a save, or end
+        std::unique_lock<std::mutex> lk(s->ctl_m);
+        if (!s->stop && !last) {
+            if (s->pause_req) {
+                w->paused = true;
+                s->ctl_cv.notify_all();
+                s->ctl_cv.wait(lk, [&] { return !s->pause_req || s->stop; });
+                w->paused = false;
+            }
+            if (!s->stop) {
+                lk.unlock();
+                if (kng_launch(w->eng) != KNG_OK) return bail(std::string("kng_launch: ") + kng_last_error());
+                continue;
+            }
+        }
+        w->ended = true;
+        s->ctl_cv.notify_all();
+        return;
+    }
+}
+
+// upload `n` kangaroos of worker w from the open work file, in chunks
+int upload_from_file(kngs_solver *s, Worker *w) {
+    const uint64_t C = 1u << 16;
+    std::vector<uint64_t> x(C * 4), y(C * 4), d(C * 4), dd(C * 2);
+    for (uint64_t c0 = 0; c0 < w->n; c0 += C) {
+        const uint64_t m = w->n - c0 < C ? w->n - c0 : C;
+        if (kngw_get_kangaroos(s->herd_file, x.data(), y.data(), d.data(), m) != 0) return fail("%s", kngw_last_error());
+        // device distances: odd (wild) indices carry +wildOffset mod n (GPUEngine.cu:406-411); c0 is even
+        if (kngh_to_device_distances(d.data(), m, s->wild_offset.v, dd.data()) != 0) return fail("restored distance does not fit 128 bits");
+        if (kng_set_kangaroos_range(w->eng, c0, m, x.data(), 4, y.data(), 4, dd.data(), 2) != KNG_OK)
+            return fail("kng_set_kangaroos_range: %s", kng_last_error());
+    }
+    s->herd_left -= w->n;
+    return 0;
+}
+
+int dump_herd(kngs_solver *s, Worker *w, kngw_file *f) {
+    const uint64_t C = 1u << 16;
+    std::vector<uint64_t> x(C * 4), y(C * 4), d(C * 4), dd(C * 2);
+    for (uint64_t c0 = 0; c0 < w->n; c0 += C) {
+        const uint64_t m = w->n - c0 < C ? w->n - c0 : C;
+        if (kng_get_kangaroos_range(w->eng, c0, m, x.data(), 4, y.data(), 4, dd.data(), 2) != KNG_OK)
+            return fail("kng_get_kangaroos_range: %s", kng_last_error());
+        kngh_to_true_distances(dd.data(), nullptr, m, s->wild_offset.v, d.data()); // c0 even: parity by position
+        if (kngw_put_kangaroos(f, x.data(), y.data(), d.data(), m) != 0) return fail("%s", kngw_last_error());
+    }
+    return 0;
+}
+
+void join_all(kngs_solver *s) {
+    if (!s->started || s->joined) return;
+    for (Worker *w : s->workers)
+        if (w->th.joinable()) w->th.join();
+    // let the consumers finish what is queued, then quit
+    while (s->inflight.load() && !s->solved && !s->failed) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    s->consumers_quit = true;
+    for (Consumer *c : s->consumers) {
+        c->cv.notify_all();
+        if (c->th.joinable()) c->th.join();
+    }
+    s->run_seconds = seconds_since(s->t_start);
+    s->joined = true;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *kngs_last_error(void) { return g_err.c_str(); }
+
+int kngs_create(const kngs_config *cfg, kngs_solver **out) {
+    if (!cfg || !out) return fail("null argument");
+    *out = nullptr;
+    if (cfg->n_gpus < 1 || cfg->n_gpus > KNGS_MAX_GPUS) return fail("n_gpus must be 1..%d", KNGS_MAX_GPUS);
+    if (std::memcmp(cfg->range_end, cfg->range_start, 32) == 0) return fail("empty range");
+    for (int i = 3; i >= 0; i--) {
+        if (cfg->range_end[i] > cfg->range_start[i]) break;
+        if (cfg->range_end[i] < cfg->range_start[i]) return fail("range end below range start");
+    }
+    if (!kngh_on_curve(cfg->key_x, cfg->key_y)) return fail("the public key does not lie on the curve");
+    kngs_solver *s = new kngs_solver();
+    s->cfg = *cfg;
+    // InitRange (Kangaroo.cpp:877-890)
+    const U256 width = sub256(cfg->range_end, cfg->range_start);
+    s->range_power = bit_length(width);
+    if (s->range_power > 125) { // device distances are 128-bit (README: 125-bit interval limit)
+        const int rp = s->range_power;
+        delete s;
+        return fail("range width 2^%d exceeds the 125-bit limit", rp);
+    }
+    s->wild_offset = shr1(width);
+    // InitSearchKey (:892-912): keyToSearch = key - rangeStart*G
+    if (is_zero(cfg->range_start)) {
+        std::memcpy(s->skx, cfg->key_x, 32);
+        std::memcpy(s->sky, cfg->key_y, 32);
+    } else {
+        uint64_t rx[4], ry[4], nry[4];
+        if (kngh_pubkey(cfg->range_start, rx, ry) != 0) {
+            delete s;
+            return fail("range start is a multiple of the group order");
+        }
+        const U256 neg = sub256(P_FIELD, ry);
+        std::memcpy(nry, neg.v, 32);
+        if (kngh_point_add(cfg->key_x, cfg->key_y, rx, nry, s->skx, s->sky) != 0) {
+            delete s;
+            return fail("the key is the start of the range"); // trivial: priv = range_start
+        }
+    }
+    kngh_jump_table(s->range_power, s->jd, s->jx, s->jy);
+    s->table = kngt_create();
+    if (!s->table) {
+        delete s;
+        return fail("out of memory");
+    }
+    *out = s;
+    return 0;
+}
+
+void kngs_destroy(kngs_solver *s) {
+    if (!s) return;
+    if (s->started && !s->joined) kngs_stop(s);
+    for (Worker *w : s->workers) {
+        if (w->eng) kng_destroy(w->eng);
+        delete w;
+    }
+    for (Consumer *c : s->consumers) delete c;
+    if (s->herd_file) kngw_close(s->herd_file);
+    kngt_destroy(s->table);
+    delete s;
+}
+
+int kngs_load(kngs_solver *s, const char *path) {
+    if (!s || !path) return fail("null argument");
+    if (s->started) return fail("kngs_load must precede kngs_start");
+    kngw_header h;
+    uint64_t n = 0;
+    kngw_file *f = kngw_open(path, &h, s->table, &n);
+    if (!f) return fail("%s", kngw_last_error());
+    if (h.magic != KNGW_HEADW) {
+        kngw_close(f);
+        return fail("%s is a kangaroo-only file; a full work file is needed", path);
+    }
+    if (!eq4(h.range_start, s->cfg.range_start) || !eq4(h.range_end, s->cfg.range_end) || !eq4(h.key_x, s->cfg.key_x) ||
+        !eq4(h.key_y, s->cfg.key_y)) {
+        kngw_close(f);
+        kngt_reset(s->table);
+        return fail("%s was made for another range or key", path);
+    }
+    if (s->cfg.dp < 0) s->cfg.dp = (int32_t)h.dp_size; // LoadWork (Backup.cpp:163): the file's DP unless forced
+    s->offset_count = h.total_count;
+    s->offset_seconds = h.total_seconds;
+    if (s->herd_file) kngw_close(s->herd_file);
+    s->herd_file = f;
+    s->herd_left = n;
+    return 0;
+}
+
+int kngs_start(kngs_solver *s) {
+    if (!s) return fail("null argument");
+    if (s->started) return fail("already started");
+    const kngs_config &cfg = s->cfg;
+    uint64_t total = 0;
+    for (int g = 0; g < cfg.n_gpus; g++) {
+        Worker *w = new Worker();
+        w->index = g;
+        w->dev = cfg.gpu_ids[g];
+        w->grid_x = cfg.grid_x;
+        w->grid_y = cfg.grid_y;
+        if (w->grid_x <= 0 || w->grid_y <= 0) {
+            if (kng_default_grid(w->dev, &w->grid_x, &w->grid_y) != KNG_OK) {
+                delete w;
+                return fail("kng_default_grid(%d): %s", cfg.gpu_ids[g], kng_last_error());
+            }
+        }
+        w->n = (uint64_t)w->grid_x * (uint64_t)w->grid_y * KNG_GRP_SIZE;
+        total += w->n;
+        s->workers.push_back(w);
+    }
+    // Run (Kangaroo.cpp:974-993): suggested DP size for the whole population
+    s->dp = cfg.dp >= 0 ? cfg.dp : kngh_suggest_dp(s->range_power, (double)total);
+    if (s->dp > 64) s->dp = 64;
+    s->dp_mask = kngh_dp_mask(s->dp);
+    for (Worker *w : s->workers) {
+        uint32_t mf = cfg.max_found;
+        if (mf == 0) {
+            const double expect = (double)w->n * KNG_NB_RUN / (s->dp >= 63 ? 9.2e18 : (double)(1ULL << s->dp));
+            const double want = 2.0 * expect < 131072.0 ? 131072.0 : 2.0 * expect;
+            mf = want > 4.0e8 ? 400000000u : (uint32_t)want;
+        }
+        if (mf > s->cfg.max_found) s->cfg.max_found = mf; // one drain buffer size for every worker
+    }
+    for (Worker *w : s->workers) {
+        if (kng_create(w->dev, w->grid_x, w->grid_y, s->cfg.max_found, &w->eng) != KNG_OK)
+            return fail("kng_create(gpu %d): %s", w->dev, kng_last_error());
+        if (kng_set_params(w->eng, s->dp_mask, s->jd, s->jx, s->jy) != KNG_OK) return fail("kng_set_params: %s", kng_last_error());
+        if (s->herd_file && s->herd_left >= w->n) {
+            if (upload_from_file(s, w) != 0) return -1;
+        } else {
+            // herd built on the device (kng_build_herd); each GPU gets its own stream of distances
+            const uint32_t windows = (uint32_t)(s->range_power + 7) / 8;
+            std::vector<uint64_t> table((size_t)windows * 256 * 8);
+            uint64_t bt[8], bw[8], fin[8];
+            const uint64_t seed = cfg.seed + 0x51ED270B1ULL * (uint64_t)(w->index + 1);
+            if (kngh_herd_params(s->range_power, s->wild_offset.v, s->skx, s->sky, seed, table.data(), bt, bw, fin) != 0)
+                return fail("kngh_herd_params failed");
+            if (kng_build_herd(w->eng, s->range_power, seed, table.data(), windows, bt, bw, fin) != KNG_OK)
+                return fail("kng_build_herd: %s", kng_last_error());
+        }
+    }
+    if (s->herd_file) {
+        kngw_close(s->herd_file);
+        s->herd_file = nullptr;
+    }
+    int nc = cfg.consumers > 0 ? cfg.consumers : (cfg.n_gpus >= 4 ? 4 : (cfg.n_gpus >= 2 ? 2 : 1));
+    for (int c = 0; c < nc; c++) s->consumers.push_back(new Consumer());
+    s->t_start = Clock::now();
+    s->started = true;
+    for (Consumer *c : s->consumers) c->th = std::thread(consumer_main, s, c);
+    for (Worker *w : s->workers) w->th = std::thread(worker_main, s, w);
+    return 0;
+}
+
+int kngs_wait(kngs_solver *s, double seconds) {
+    if (!s) return fail("null argument");
+    if (!s->started) return fail("not started");
+    std::unique_lock<std::mutex> lk(s->ctl_m);
+    auto all_ended = [&] {
+        for (Worker *w : s->workers)
+            if (!w->ended) return false;
+        return true;
+    };
+    const auto deadline = Clock::now() + std::chrono::duration_cast<Clock::duration>(std::chrono::duration<double>(seconds));
+    while (!s->solved && !s->failed && !all_ended()) {
+        if (s->ctl_cv.wait_until(lk, deadline) == std::cv_status::timeout) break;
+    }
+    if (s->failed) return fail("%s", s->error.c_str());
+    if (s->solved) return 1;
+    if (all_ended()) {
+        lk.unlock();
+        // the last batches may still be on their way into the table
+        while (s->inflight.load() && !s->solved && !s->failed) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        if (s->failed) return fail("%s", s->error.c_str());
+        return s->solved ? 1 : 2;
+    }
+    return 0;
+}
+
+int kngs_stop(kngs_solver *s) {
+    if (!s) return fail("null argument");
+    if (!s->started) return 0;
+    s->stop = true;
+    s->ctl_cv.notify_all();
+    join_all(s);
+    if (s->failed) return fail("%s", s->error.c_str());
+    return 0;
+}
+
+int kngs_result(const kngs_solver *s, uint64_t priv[4]) {
+    if (!s || !priv) return fail("null argument");
+    if (!s->solved) return fail("not solved");
+    std::memcpy(priv, s->priv, 32);
+    return 0;
+}
+
+int kngs_get_stats(const kngs_solver *s, kngs_stats *st) {
+    if (!s || !st) return fail("null argument");
+    std::memset(st, 0, sizeof *st);
+    double kms = 0;
+    int running = 0;
+    for (const Worker *w : s->workers) {
+        const uint64_t l = w->launches.load();
+        st->launches += l;
+        st->jumps += l * w->n * KNG_NB_RUN;
+        st->kangaroos += w->n;
+        kms += w->kernel_ms_sum;
+        if (!w->ended) running++;
+    }
+    st->jumps += s->offset_count;
+    st->dps = s->dps;
+    st->dps_lost = s->dps_lost;
+    st->same_herd = s->same_herd;
+    st->wrong_collisions = s->wrong;
+    st->table_items = s->joined ? kngt_count(s->table) : 0; // exact only when the consumers are quiet
+    st->seconds = s->offset_seconds + (s->started ? (s->joined ? s->run_seconds : seconds_since(s->t_start)) : 0.0);
+    st->kernel_ms_avg = st->launches ? kms / (double)st->launches : 0.0;
+    st->dp = s->dp;
+    st->range_power = s->range_power;
+    st->solved = s->solved ? 1 : 0;
+    st->running = s->started && !s->joined ? running : 0;
+    return 0;
+}
+
+int kngs_save(kngs_solver *s, const char *path, int with_kangaroos) {
+    if (!s || !path) return fail("null argument");
+    if (!s->started) return fail("not started");
+    std::lock_guard<std::mutex> save_lock(s->save_m);
+    // SaveWork (Backup.cpp:446-470): wait until every thread blocks at a launch boundary
+    s->pause_req = 1;
+    {
+        std::unique_lock<std::mutex> lk(s->ctl_m);
+        s->ctl_cv.wait(lk, [&] {
+            for (Worker *w : s->workers)
+                if (!w->paused && !w->ended) return false;
+            return true;
+        });
+    }
+    while (s->inflight.load() && !s->failed) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    int rc = 0;
+    kngs_stats st;
+    kngs_get_stats(s, &st);
+    kngw_header h;
+    std::memset(&h, 0, sizeof h);
+    h.magic = KNGW_HEADW;
+    h.dp_size = (uint32_t)s->dp;
+    std::memcpy(h.range_start, s->cfg.range_start, 32);
+    std::memcpy(h.range_end, s->cfg.range_end, 32);
+    std::memcpy(h.key_x, s->cfg.key_x, 32);
+    std::memcpy(h.key_y, s->cfg.key_y, 32);
+    h.total_count = st.jumps;
+    h.total_seconds = st.seconds;
+    kngw_file *f = kngw_create(path, &h, s->table, with_kangaroos ? st.kangaroos : 0);
+    if (!f) {
+        rc = fail("%s", kngw_last_error());
+    } else {
+        if (with_kangaroos)
+            for (Worker *w : s->workers)
+                if (rc == 0) rc = dump_herd(s, w, f); // the worker threads are parked: the engines are ours
+        const std::string keep = g_err;
+        if (kngw_close(f) != 0 && rc == 0) rc = fail("%s", kngw_last_error());
+        else if (rc != 0) g_err = keep;
+    }
+    {
+        std::lock_guard<std::mutex> g(s->ctl_m);
+        s->pause_req = 0;
+    }
+    s->ctl_cv.notify_all();
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,85 @@
+/*
+ * kng_solver.h -- multi-GPU host pipeline around the MI355X jump engine (libkangaroo_host.so).
+ *
+ * SURVEY 8(f) row 1 (+ rows 3, 4): what Kangaroo::SolveKeyGPU (Kangaroo.cpp:510-644) and its helpers
+ * AddToTable/CollisionCheck/CheckKey (:233-329) do around class GPUEngine, rebuilt so that the host never
+ * limits the engines:
+ *   - one host thread per GPU drives kng_launch / kng_wait / kng_drain and starts launch k+1 BEFORE it
+ *     touches the distinguished points of launch k (the reference inserts them under one global mutex
+ *     between two launches, :594-612);
+ *   - DPs are converted to hash-table entries on the GPU thread and handed, in batches, to consumer
+ *     threads that each own a fixed subset of the 2^18 buckets (kng_dptable.h) -- no global lock;
+ *   - a kangaroo that fell into the trail of one of its own herd (DUPLICATE / same-type collision,
+ *     :599-606) is replaced with kng_set_kangaroo, stream-ordered, without stalling the GPU;
+ *   - a tame/wild collision is resolved with the reference's four sign combinations (:233-268);
+ *   - work files (kng_workfile.h) are saved at a launch boundary and restored, herd included, in the
+ *     reference's format.
+ * Same mathematics as the reference: jump table (seed 0x600DCAFE), DP size suggestion, wild offset
+ * rangeWidth/2, keyToSearch = key - rangeStart*G (Kangaroo.cpp:835-905).  Not rebuilt: the CLI, the
+ * client/server mode, CPU worker threads, merging tools.
+ *
+ * There is no CPU fallback: kngs_start fails when an engine cannot be created.
+ */
+#ifndef KNG_SOLVER_H
+#define KNG_SOLVER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KNGS_MAX_GPUS 16
+
+typedef struct kngs_config {
+    uint64_t range_start[4], range_end[4]; /* inclusive range of the private key */
+    uint64_t key_x[4], key_y[4];           /* public key to solve */
+    int32_t dp;                            /* distinguished-point bits; -1 = suggested (Kangaroo.cpp:980-993) */
+    int32_t n_gpus;
+    int32_t gpu_ids[KNGS_MAX_GPUS];
+    int32_t grid_x, grid_y; /* <=0: kng_default_grid of each device */
+    uint32_t max_found;     /* DP slots per launch; 0 = max(131072, 2 x expected) */
+    int32_t consumers;      /* hash-table threads; 0 = automatic */
+    uint64_t seed;          /* herd seed (the reference seeds from the clock) */
+    uint64_t max_launches;  /* per GPU, 0 = until solved or stopped */
+} kngs_config;
+
+typedef struct kngs_stats {
+    uint64_t jumps;            /* incl. the count restored from a work file */
+    uint64_t launches;         /* summed over GPUs, this run */
+    uint64_t dps;              /* distinguished points received from the GPUs */
+    uint64_t dps_lost;         /* dropped because max_found was exceeded */
+    uint64_t same_herd;        /* kangaroos replaced: duplicate point or same-type collision */
+    uint64_t wrong_collisions; /* tame/wild collisions that did not resolve (should stay 0) */
+    uint64_t table_items;
+    uint64_t kangaroos;        /* total over GPUs */
+    double seconds;            /* wall time since kngs_start (plus restored time) */
+    double kernel_ms_avg;      /* mean walk-kernel duration over GPUs and launches */
+    int32_t dp, range_power, solved, running;
+} kngs_stats;
+
+typedef struct kngs_solver kngs_solver;
+
+int kngs_create(const kngs_config *cfg, kngs_solver **out);
+void kngs_destroy(kngs_solver *s);
+/* restore hash table, counters and (when the file has them) herds from a HEADW work file written by this
+ * library or by the reference; range and key must match the configuration.  Call before kngs_start. */
+int kngs_load(kngs_solver *s, const char *path);
+/* create the engines, build or upload the herds, start the GPU and consumer threads */
+int kngs_start(kngs_solver *s);
+/* block until solved (returns 1), every GPU has done max_launches (2), or `seconds` elapsed (0); <0 error */
+int kngs_wait(kngs_solver *s, double seconds);
+/* ask the threads to stop after their current launch and join them */
+int kngs_stop(kngs_solver *s);
+/* the private key, valid once solved (kngs_wait returned 1); returns 0, or -1 when not solved */
+int kngs_result(const kngs_solver *s, uint64_t priv[4]);
+int kngs_get_stats(const kngs_solver *s, kngs_stats *st);
+/* save a HEADW work file at the next launch boundary (GPUs pause, resume afterwards); with_kangaroos != 0
+ * appends every herd (96 B per kangaroo, GPU order) like -ws.  Works while running and after kngs_stop. */
+int kngs_save(kngs_solver *s, const char *path, int with_kangaroos);
+const char *kngs_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

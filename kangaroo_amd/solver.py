@@ -1,0 +1,246 @@
+"""ctypes binding of the host pipeline in libkangaroo_host.so (kangaroo_amd/host/):
+
+  DpTable   -- kng_dptable.h: the distinguished-point table, serialisation-compatible with the reference's
+               HashTable (HashTable.cpp:75-100,262-307,375-396)
+  WorkFile  -- kng_workfile.h: work files in the reference's format (Backup.cpp:368-407,497-552)
+  Solver    -- kng_solver.h: multi-GPU SolveKeyGPU replacement (Kangaroo.cpp:510-644) with an asynchronous
+               DP drain, sharded table, stream-ordered kangaroo replacement, save/restore
+
+Product-side code; the heavy lifting is C++.  Nothing here falls back to the CPU: Solver.start() raises when
+an engine cannot be created.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import hostlib
+from .hostlib import limbs, to_int
+
+_U64P = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+ADD_OK, ADD_DUPLICATE, ADD_COLLISION = 0, 1, 2
+HEADW, HEADK = 0xFA6A8001, 0xFA6A8002
+N_BUCKETS = 1 << 18
+MAX_GPUS = 16
+
+ENTRY_DTYPE = np.dtype([("x", np.uint64, (2,)), ("d", np.uint64, (2,))])
+
+
+class _Header(C.Structure):
+    _fields_ = [("magic", C.c_uint32), ("version", C.c_uint32), ("dp_size", C.c_uint32), ("reserved", C.c_uint32),
+                ("range_start", C.c_uint64 * 4), ("range_end", C.c_uint64 * 4), ("key_x", C.c_uint64 * 4),
+                ("key_y", C.c_uint64 * 4), ("total_count", C.c_uint64), ("total_seconds", C.c_double)]
+
+
+class _Config(C.Structure):
+    _fields_ = [("range_start", C.c_uint64 * 4), ("range_end", C.c_uint64 * 4), ("key_x", C.c_uint64 * 4),
+                ("key_y", C.c_uint64 * 4), ("dp", C.c_int32), ("n_gpus", C.c_int32), ("gpu_ids", C.c_int32 * MAX_GPUS),
+                ("grid_x", C.c_int32), ("grid_y", C.c_int32), ("max_found", C.c_uint32), ("consumers", C.c_int32),
+                ("seed", C.c_uint64), ("max_launches", C.c_uint64)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("jumps", C.c_uint64), ("launches", C.c_uint64), ("dps", C.c_uint64), ("dps_lost", C.c_uint64),
+                ("same_herd", C.c_uint64), ("wrong_collisions", C.c_uint64), ("table_items", C.c_uint64),
+                ("kangaroos", C.c_uint64), ("seconds", C.c_double), ("kernel_ms_avg", C.c_double), ("dp", C.c_int32),
+                ("range_power", C.c_int32), ("solved", C.c_int32), ("running", C.c_int32)]
+
+
+_bound = False
+
+
+def _lib() -> C.CDLL:
+    global _bound
+    L = hostlib.load()
+    if not _bound:
+        L.kngt_create.restype = C.c_void_p
+        L.kngt_destroy.argtypes = [C.c_void_p]
+        L.kngt_destroy.restype = None
+        L.kngt_reset.argtypes = [C.c_void_p]
+        L.kngt_reset.restype = None
+        L.kngt_add.argtypes = [C.c_void_p, _U64P, _U64P, C.c_uint32, _U64P, C.POINTER(C.c_uint32)]
+        L.kngt_count.argtypes = [C.c_void_p]
+        L.kngt_count.restype = C.c_uint64
+        L.kngt_bucket_count.argtypes = [C.c_void_p, C.c_uint32]
+        L.kngt_bucket_count.restype = C.c_uint32
+        L.kngt_bucket_entries.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.kngt_bucket_entries.restype = C.c_uint32
+        L.kngt_serialised_size.argtypes = [C.c_void_p]
+        L.kngt_serialised_size.restype = C.c_uint64
+        L.kngw_create.argtypes = [C.c_char_p, C.POINTER(_Header), C.c_void_p, C.c_uint64]
+        L.kngw_create.restype = C.c_void_p
+        L.kngw_put_kangaroos.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_uint64]
+        L.kngw_open.argtypes = [C.c_char_p, C.POINTER(_Header), C.c_void_p, C.POINTER(C.c_uint64)]
+        L.kngw_open.restype = C.c_void_p
+        L.kngw_get_kangaroos.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, C.c_uint64]
+        L.kngw_close.argtypes = [C.c_void_p]
+        L.kngw_last_error.restype = C.c_char_p
+        L.kngs_create.argtypes = [C.POINTER(_Config), C.POINTER(C.c_void_p)]
+        L.kngs_destroy.argtypes = [C.c_void_p]
+        L.kngs_destroy.restype = None
+        L.kngs_load.argtypes = [C.c_void_p, C.c_char_p]
+        L.kngs_start.argtypes = [C.c_void_p]
+        L.kngs_wait.argtypes = [C.c_void_p, C.c_double]
+        L.kngs_stop.argtypes = [C.c_void_p]
+        L.kngs_result.argtypes = [C.c_void_p, _U64P]
+        L.kngs_get_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
+        L.kngs_save.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.kngs_last_error.restype = C.c_char_p
+        _bound = True
+    return L
+
+
+class HostError(RuntimeError):
+    pass
+
+
+class DpTable:
+    """HashTable (HashTable.h:58-100): Add / GetNbItem / Reset + access to the sorted buckets."""
+
+    def __init__(self):
+        self._L = _lib()
+        self._h = self._L.kngt_create()
+        if not self._h:
+            raise MemoryError("kngt_create")
+
+    def close(self):
+        if self._h:
+            self._L.kngt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add(self, x: int, d: int, ktype: int):
+        """Returns (status, other_d, other_type); other_* describe the stored kangaroo on ADD_COLLISION."""
+        od = np.zeros(4, np.uint64)
+        ot = C.c_uint32(0)
+        st = self._L.kngt_add(self._h, limbs(x), limbs(d), ktype, od, C.byref(ot))
+        if st < 0:
+            raise MemoryError("kngt_add")
+        return (st, to_int(od), int(ot.value)) if st == ADD_COLLISION else (st, None, None)
+
+    def count(self) -> int:
+        return int(self._L.kngt_count(self._h))
+
+    def reset(self):
+        self._L.kngt_reset(self._h)
+
+    def bucket(self, h: int) -> np.ndarray:
+        n = int(self._L.kngt_bucket_count(self._h, h))
+        out = np.zeros(n, ENTRY_DTYPE)
+        if n:
+            self._L.kngt_bucket_entries(self._h, h, out.ctypes.data, n)
+        return out
+
+    def serialised_size(self) -> int:
+        return int(self._L.kngt_serialised_size(self._h))
+
+
+def _hdr_to_dict(h: _Header) -> dict:
+    return dict(magic=h.magic, version=h.version, dp=h.dp_size, range_start=to_int(h.range_start), range_end=to_int(h.range_end),
+                key=(to_int(h.key_x), to_int(h.key_y)), count=int(h.total_count), seconds=float(h.total_seconds))
+
+
+def write_workfile(path: str, *, dp: int, range_start: int, range_end: int, key, count: int, seconds: float, table: DpTable,
+                   kangaroos=None, magic: int = HEADW) -> None:
+    """kangaroos: None or (x, y, d_true) arrays of shape (n, 4)."""
+    L = _lib()
+    h = _Header(magic=magic, version=0, dp_size=dp, total_count=count, total_seconds=seconds)
+    for name, v in (("range_start", range_start), ("range_end", range_end), ("key_x", key[0]), ("key_y", key[1])):
+        for i in range(4):
+            getattr(h, name)[i] = (v >> (64 * i)) & ((1 << 64) - 1)
+    n = 0 if kangaroos is None else len(kangaroos[0])
+    f = L.kngw_create(path.encode(), C.byref(h), table._h if table is not None else None, n)
+    if not f:
+        raise HostError(L.kngw_last_error().decode())
+    if n:
+        x, y, d = (np.ascontiguousarray(a, dtype=np.uint64) for a in kangaroos)
+        if L.kngw_put_kangaroos(f, x, y, d, n) != 0:
+            L.kngw_close(f)
+            raise HostError(L.kngw_last_error().decode())
+    if L.kngw_close(f) != 0:
+        raise HostError(L.kngw_last_error().decode())
+
+
+def read_workfile(path: str, table: DpTable | None = None, with_kangaroos: bool = True):
+    """Returns (header dict, n_kangaroos, (x, y, d_true) or None); fills `table` when given."""
+    L = _lib()
+    h = _Header()
+    n = C.c_uint64(0)
+    f = L.kngw_open(path.encode(), C.byref(h), table._h if table is not None else None, C.byref(n))
+    if not f:
+        raise HostError(L.kngw_last_error().decode())
+    kang = None
+    if with_kangaroos and n.value:
+        x, y, d = (np.zeros((n.value, 4), np.uint64) for _ in range(3))
+        if L.kngw_get_kangaroos(f, x, y, d, n.value) != 0:
+            L.kngw_close(f)
+            raise HostError(L.kngw_last_error().decode())
+        kang = (x, y, d)
+    L.kngw_close(f)
+    return _hdr_to_dict(h), int(n.value), kang
+
+
+class Solver:
+    """Kangaroo::SolveKeyGPU for N GPUs (Kangaroo.cpp:510-644, :1019-1063) over the C-ABI engine."""
+
+    def __init__(self, range_start: int, range_end: int, key, *, gpus=(0,), grid=(0, 0), dp: int = -1, max_found: int = 0,
+                 consumers: int = 0, seed: int = 1, max_launches: int = 0):
+        self._L = _lib()
+        cfg = _Config(dp=dp, n_gpus=len(gpus), grid_x=grid[0], grid_y=grid[1], max_found=max_found, consumers=consumers,
+                      seed=seed & ((1 << 64) - 1), max_launches=max_launches)
+        for name, v in (("range_start", range_start), ("range_end", range_end), ("key_x", key[0]), ("key_y", key[1])):
+            for i in range(4):
+                getattr(cfg, name)[i] = (v >> (64 * i)) & ((1 << 64) - 1)
+        for i, g in enumerate(gpus):
+            cfg.gpu_ids[i] = g
+        self._h = C.c_void_p()
+        if self._L.kngs_create(C.byref(cfg), C.byref(self._h)) != 0:
+            raise HostError(self._L.kngs_last_error().decode())
+
+    def _check(self, rc: int) -> int:
+        if rc < 0:
+            raise HostError(self._L.kngs_last_error().decode())
+        return rc
+
+    def close(self):
+        if self._h:
+            self._L.kngs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load(self, path: str):
+        self._check(self._L.kngs_load(self._h, path.encode()))
+
+    def start(self):
+        self._check(self._L.kngs_start(self._h))
+
+    def wait(self, seconds: float) -> int:
+        """1 = solved, 2 = every GPU reached max_launches, 0 = timeout."""
+        return self._check(self._L.kngs_wait(self._h, seconds))
+
+    def stop(self):
+        self._check(self._L.kngs_stop(self._h))
+
+    def result(self) -> int:
+        out = np.zeros(4, np.uint64)
+        self._check(self._L.kngs_result(self._h, out))
+        return to_int(out)
+
+    def stats(self) -> dict:
+        st = _Stats()
+        self._check(self._L.kngs_get_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in _Stats._fields_}
+
+    def save(self, path: str, with_kangaroos: bool = True):
+        self._check(self._L.kngs_save(self._h, path.encode(), 1 if with_kangaroos else 0))

@@ -11,6 +11,7 @@
  * against that file.
  *
  * usage: refprobe <out.json> [seed]
+ *        refprobe --hashtable <out.json> [seed]
  */
 #include <cinttypes>
 #include <cstdio>
@@ -285,10 +286,70 @@ static void emit_walk(Secp256K1 *secp, const char *name, const char *start_hex, 
   delete kg;
 }
 
+/* HashTable KATs: a seeded add sequence through the reference's HashTable::Add
+ * (duplicates, collisions, negative distances, buckets grown past 16/20/24 items) with every status,
+ * the collision read-back, and the final content of every non-empty bucket incl. the maxItem word. */
+static void emit_hashtable(const char *path, uint32_t seed) {
+  FILE *f = fopen(path, "w");
+  if (!f) exit(1);
+  rseed(seed);
+  HashTable *ht = new HashTable();
+  Secp256K1 *secp = new Secp256K1();
+  secp->Init();
+  std::vector<Int> xs, ds;
+  std::vector<uint32_t> types;
+  const uint64_t hot[3] = {0x2A5F1, 0x00000, 0x3FFFF};
+  for (int i = 0; i < 900; i++) {
+    Int x, d;
+    x.Rand(256);
+    int mode = (int)(rndl() % 10);
+    if (mode < 6) x.bits64[2] = (x.bits64[2] & ~0x3FFFFULL) | hot[rndl() % 3]; /* crowd three buckets */
+    if (mode == 6) x.bits64[1] = xs.empty() ? x.bits64[1] : xs[rndl() % xs.size()].bits64[1]; /* equal high word */
+    d.Rand(126);
+    if (rndl() % 3 == 0) d.ModNegK1order(); /* negative distance: n - d */
+    uint32_t type = (uint32_t)(rndl() & 1);
+    if (!xs.empty() && mode == 7) { /* exact repeat */
+      size_t k = rndl() % xs.size();
+      x.Set(&xs[k]); d.Set(&ds[k]); type = types[k];
+    } else if (!xs.empty() && mode == 8) { /* same x, other distance/type: collision */
+      size_t k = rndl() % xs.size();
+      x.Set(&xs[k]);
+    }
+    xs.push_back(x); ds.push_back(d); types.push_back(type);
+  }
+  fprintf(f, "{\"generator\":\"oracle/refprobe.cpp --hashtable, reference HashTable::Add\",\"seed\":%u,\n\"adds\":[\n", seed);
+  for (size_t i = 0; i < xs.size(); i++) {
+    int st = ht->Add(&xs[i], &ds[i], types[i]);
+    fprintf(f, "[\"%s\",\"%s\",%u,%d", hex4(xs[i]).c_str(), hex4(ds[i]).c_str(), types[i], st);
+    if (st == ADD_COLLISION) fprintf(f, ",\"%s\",%u", hex4(ht->kDist).c_str(), ht->kType);
+    fprintf(f, "]%s\n", i + 1 < xs.size() ? "," : "");
+  }
+  fprintf(f, "],\n\"count\":%" PRIu64 ",\n\"buckets\":[\n", ht->GetNbItem());
+  bool first = true;
+  for (uint32_t h = 0; h < HASH_SIZE; h++) {
+    if (ht->E[h].nbItem == 0 && ht->E[h].maxItem == 0) continue;
+    fprintf(f, "%s[%u,%u,%u,[", first ? "" : ",\n", h, ht->E[h].nbItem, ht->E[h].maxItem);
+    first = false;
+    for (uint32_t i = 0; i < ht->E[h].nbItem; i++) {
+      ENTRY *e = ht->E[h].items[i];
+      fprintf(f, "%s\"%016" PRIx64 "%016" PRIx64 "%016" PRIx64 "%016" PRIx64 "\"", i ? "," : "", e->x.i64[0], e->x.i64[1],
+              e->d.i64[0], e->d.i64[1]);
+    }
+    fprintf(f, "]]");
+  }
+  fprintf(f, "\n]}\n");
+  fclose(f);
+}
+
 int main(int argc, char **argv) {
   if (argc < 2) {
     fprintf(stderr, "usage: %s <out.json> [seed]\n", argv[0]);
     return 2;
+  }
+  if (argc >= 3 && std::string(argv[1]) == "--hashtable") {
+    Timer::Init();
+    emit_hashtable(argv[2], argc > 3 ? (uint32_t)strtoul(argv[3], NULL, 0) : 0x7AB1E001u);
+    return 0;
   }
   uint32_t seed = argc > 2 ? (uint32_t)strtoul(argv[2], NULL, 0) : 0x5EED1234u;
   out = fopen(argv[1], "w");

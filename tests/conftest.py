@@ -25,3 +25,15 @@ def orc():
     from oracle import load_oracle
 
     return load_oracle()
+
+
+@pytest.fixture(scope="session")
+def kng():
+    """The engine library on a real device (GPU tests only): raises instead of falling back."""
+    import kangaroo_amd
+
+    kangaroo_amd.load_library()  # raises if the HIP library was not built: no fallback
+    assert kangaroo_amd.device_count() >= 1, "no HIP device visible"
+    info = kangaroo_amd.device_info(0)
+    assert "gfx950" in info["arch"], info
+    return kangaroo_amd

@@ -20,17 +20,6 @@ pytestmark = pytest.mark.gpu
 H = lambda s: int(s, 16)  # noqa: E731
 
 
-@pytest.fixture(scope="module")
-def kng():
-    import kangaroo_amd
-
-    kangaroo_amd.load_library()  # raises if the HIP library was not built: no fallback
-    assert kangaroo_amd.device_count() >= 1, "no HIP device visible"
-    info = kangaroo_amd.device_info(0)
-    assert "gfx950" in info["arch"], info
-    return kangaroo_amd
-
-
 # ------------------------------------------------------------------ primitives
 def _pairs(vecs):
     a = ints_to_array([H(v[0]) for v in vecs])
