@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--group", type=int, default=0, help="kangaroos per lane (0 = engine default)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the end-to-end host-pipeline sample (N=1 only)")
     ap.add_argument("--host-herd", action="store_true", help="build the herd on the host and upload it (default: on the GPU)")
     args = ap.parse_args()
 
@@ -253,6 +254,24 @@ def main():
         },
     }
     eng.close()
+    if rank == 0 and n_gpus == 1 and not args.no_pipeline:
+        # reported next to the hot-path figure, never instead of it: the same workload through the host
+        # pipeline (kangaroo_amd/host/kng_solver.cpp): every DP converted, queued and inserted into the table
+        try:
+            from kangaroo_amd import solver as sv
+
+            s = sv.Solver(RANGE_START, RANGE_START + (1 << RANGE_POWER) - 1, (kx, ky), gpus=(local_rank,), grid=(gx, gy), dp=dp,
+                          seed=0x5EED, max_launches=max(10, args.steps))
+            s.start()
+            s.wait(120)
+            st = s.stats()
+            s.stop()
+            s.close()
+            out["pipeline"] = {"value": round(st["jumps"] / st["seconds"] / 1e6, 2), "unit": "MK/s", "launches": st["launches"],
+                               "kernel_ms_avg": round(st["kernel_ms_avg"], 3), "dps": st["dps"], "dps_lost": st["dps_lost"],
+                               "what": "kngs_* solver: async DP drain + sharded DP table, wall clock incl. first and last launch"}
+        except Exception as e:
+            out["pipeline"] = {"value": None, "unit": "MK/s", "what": f"failed: {e}"}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline()

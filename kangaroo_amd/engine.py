@@ -61,6 +61,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.kng_set_params.argtypes = [C.c_void_p, C.c_uint64, _U64P, _U64P, _U64P]
     L.kng_set_kangaroos.argtypes = [C.c_void_p, _U64P, C.c_size_t, _U64P, C.c_size_t, _U64P, C.c_size_t, C.c_uint64]
     L.kng_get_kangaroos.argtypes = [C.c_void_p, _U64P, C.c_size_t, _U64P, C.c_size_t, _U64P, C.c_size_t, C.c_uint64]
+    L.kng_set_kangaroos_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, _U64P, C.c_size_t, _U64P, C.c_size_t, _U64P, C.c_size_t]
+    L.kng_get_kangaroos_range.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, _U64P, C.c_size_t, _U64P, C.c_size_t, _U64P, C.c_size_t]
     L.kng_set_kangaroo.argtypes = [C.c_void_p, C.c_uint64, _U64P, _U64P, _U64P]
     L.kng_build_herd.argtypes = [C.c_void_p, C.c_int, C.c_uint64, _U64P, C.c_uint32, _U64P, _U64P, _U64P]
     L.kng_build_herd.restype = C.c_int
@@ -72,7 +74,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.kng_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
     L.kng_test_fieldop.argtypes = [C.c_int, C.c_int, _U64P, _U64P, _U64P, C.c_uint64]
     for name in ("kng_device_info", "kng_default_grid", "kng_create", "kng_set_params", "kng_set_kangaroos",
-                 "kng_get_kangaroos", "kng_set_kangaroo", "kng_launch", "kng_wait", "kng_drain",
+                 "kng_get_kangaroos", "kng_set_kangaroos_range", "kng_get_kangaroos_range", "kng_set_kangaroo", "kng_launch", "kng_wait", "kng_drain",
                  "kng_last_kernel_ms", "kng_set_option", "kng_get_option", "kng_test_fieldop"):
         getattr(L, name).restype = C.c_int
     _lib = L
@@ -235,6 +237,22 @@ class GPUEngine:
         dd = np.zeros((n, 2), dtype=np.uint64)
         _check(self._L.kng_get_kangaroos(self._h, px, 4, py, 4, dd, 2, n))
         return px, py, (dd if raw else self._to_true_d(dd))
+
+    def SetKangaroosRange(self, first: int, px: np.ndarray, py: np.ndarray, dd: np.ndarray) -> None:
+        """Upload kangaroos first .. first+len-1 (kng_set_kangaroos_range); dd: (m,2) DEVICE distances.  The herd
+        counts as loaded once a range ending at the last kangaroo has been set."""
+        px = np.ascontiguousarray(px, dtype=np.uint64)
+        py = np.ascontiguousarray(py, dtype=np.uint64)
+        dd = np.ascontiguousarray(dd, dtype=np.uint64)
+        _check(self._L.kng_set_kangaroos_range(self._h, first, px.shape[0], px, 4, py, 4, dd, 2))
+
+    def GetKangaroosRange(self, first: int, count: int):
+        """(x, y, device distances) of kangaroos first .. first+count-1 (kng_get_kangaroos_range)."""
+        px = np.zeros((count, 4), dtype=np.uint64)
+        py = np.zeros((count, 4), dtype=np.uint64)
+        dd = np.zeros((count, 2), dtype=np.uint64)
+        _check(self._L.kng_get_kangaroos_range(self._h, first, count, px, 4, py, 4, dd, 2))
+        return px, py, dd
 
     def CreateHerdOnDevice(self, range_power: int, key_xy=None, seed: int = 1) -> int:
         """Build the whole herd on the GPU (kng_build_herd; replaces Kangaroo::CreateHerd + SetKangaroos).

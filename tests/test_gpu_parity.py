@@ -575,6 +575,36 @@ def test_ragged_groups_vs_oracle(kng, orc, grid, lanes, arith):
     eng.close()
 
 
+@pytest.mark.parametrize("arith", [32, 29])
+def test_ranged_set_get_of_the_herd(kng, arith):
+    """kng_set_kangaroos_range / kng_get_kangaroos_range: the herd uploaded in uneven slices (crossing the 64 K
+    staging chunk) equals a whole-herd upload, slices read back equal the whole-herd read, bad ranges are refused."""
+    gx, gy = 40, 16  # 81 920 kangaroos: more than one staging chunk
+    n = gx * gy * 128
+    rng = np.random.default_rng(77)
+    x = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    y = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    x[:, 3] >>= np.uint64(2)
+    y[:, 3] >>= np.uint64(2)
+    d = rng.integers(0, 1 << 64, size=(n, 2), dtype=np.uint64)
+    eng = kng.GPUEngine(gx, gy, 0, 1 << 16, arith=arith)
+    cuts = [0, 1, 4097, 65536, 65537, 70001, n]
+    with pytest.raises(kng.EngineError):
+        eng.GetKangaroosRange(0, 16)  # nothing loaded yet
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        eng.SetKangaroosRange(a, x[a:b], y[a:b], d[a:b])
+    gx_, gy_, gd_ = eng.GetKangaroos(raw=True)
+    assert np.array_equal(gx_, x) and np.array_equal(gy_, y) and np.array_equal(gd_, d)
+    for a, b in ((0, 5), (65530, 65550), (n - 3, n), (12345, 12345)):
+        sx, sy, sd = eng.GetKangaroosRange(a, b - a)
+        assert np.array_equal(sx, x[a:b]) and np.array_equal(sy, y[a:b]) and np.array_equal(sd, d[a:b])
+    with pytest.raises(kng.EngineError, match="outside the herd"):
+        eng.GetKangaroosRange(n - 2, 3)
+    with pytest.raises(kng.EngineError, match="outside the herd"):
+        eng.SetKangaroosRange(n, x[:1], y[:1], d[:1])
+    eng.close()
+
+
 @pytest.mark.parametrize("share", [2, 3])
 @pytest.mark.parametrize("grid,opt", [((4, 4), dict(group=4)), ((4, 4), dict(group=128)), ((3, 5), dict(lanes=448)),
                                       ((2, 3), dict(lanes=320)), ((8, 4), dict(group=2))])

@@ -5,7 +5,7 @@ TAG=$1
 OUT=$PWD/gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
 for SET in "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VMEM SQ_WAVE_CYCLES" "SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU"; do
-  (cd /tmp && rocprofv3 --pmc $SET --output-format csv -d $OUT/${TAG}_lat -o lat -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_lat.err)
+  (cd /tmp && rocprofv3 --pmc $SET --output-format csv -d $OUT/${TAG}_lat -o lat -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline > /dev/null 2> $OUT/${TAG}_lat.err)
   f=$(find $OUT/${TAG}_lat -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python - "$f" <<'PY'
 import csv, sys
