@@ -27,6 +27,38 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/kangaroo_hip.h but not exported"
 
 
+def test_host_library_exports_every_declared_symbol_and_headers_are_plain_c():
+    """libkangaroo_host.so: every kngh_/kngt_/kngw_/kngs_ function of kangaroo_amd/host/*.h is exported and the
+    headers compile as C99 (they are the binding surface for the host pipeline)."""
+    import ctypes
+    import subprocess
+    import tempfile
+
+    from kangaroo_amd import hostlib
+
+    lib = hostlib.load()
+    assert isinstance(lib, ctypes.CDLL)
+    host = os.path.join(ROOT, "kangaroo_amd", "host")
+    total = 0
+    for hdr, prefix in (("kng_host.h", "kngh_"), ("kng_dptable.h", "kngt_"), ("kng_workfile.h", "kngw_"), ("kng_solver.h", "kngs_")):
+        with open(os.path.join(host, hdr)) as f:
+            src = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+        names = sorted(set(re.findall(r"\b(%s[a-z_0-9]+)\s*\(" % prefix, src)))
+        assert names, hdr
+        total += len(names)
+        for name in names:
+            assert hasattr(lib, name), f"{name} declared in {hdr} but not exported"
+    assert total >= 40
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "t.c")
+        with open(src, "w") as f:
+            f.write('#include "kng_host.h"\n#include "kng_dptable.h"\n#include "kng_workfile.h"\n#include "kng_solver.h"\n'
+                    "int main(void){return sizeof(kngt_entry)==32 ? 0 : 1;}\n")
+        exe = os.path.join(td, "t")
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", host, src, "-o", exe])
+        assert subprocess.call([exe]) == 0
+
+
 def test_header_is_plain_c():
     import subprocess
     import tempfile

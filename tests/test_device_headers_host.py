@@ -55,6 +55,13 @@ def test_modinv_safegcd_and_fermat(golden, host_field):
     want = [int(r, 16) % P for _, r in inv]
     assert host_field([f"inv {a} {a}" for a, _ in inv]) == want
     assert host_field([f"invf {a} {a}" for a, _ in inv]) == want
+    # the packed 2 x 15-step division steps against Fermat on seeded values of every size
+    import random
+
+    rnd = random.Random(0xD1F5)
+    vals = [rnd.getrandbits(rnd.choice((8, 31, 64, 129, 200, 255, 256))) % P or 1 for _ in range(3000)]
+    vals += [1, 2, P - 1, P - 2, (P + 1) // 2, 1 << 255, (1 << 256) - 1 - P]
+    assert host_field([f"inv {v:064x} {v:064x}" for v in vals]) == [pow(v, P - 2, P) for v in vals]
 
 
 def test_radix29_ops_match_canonical_arithmetic(golden, host_field):

@@ -76,7 +76,9 @@ def test_tiny_range_replaces_same_herd_kangaroos(sv):
     s.close()
 
 
-def test_save_restore_continue_and_reference_reads_it(sv, orc, tmp_path):
+@pytest.mark.parametrize("start,rp,key_off", [(0x3C0FFEE00000000000000000, 70, 0x2B5E6F7A8C9D0E1F23),
+                                              (0, 125, 0x12345678FEDCBA9876543210DEADBEEF)])
+def test_save_restore_continue_and_reference_reads_it(sv, orc, tmp_path, start, rp, key_off):
     """Run a few launches, save with kangaroos, restore into a new solver, run exactly one launch, save again:
     - the reference program accepts the first file (-winfo, -wcheck: every DP re-derived from its distance);
     - the restored herd after one launch equals the oracle walking the SAVED herd 64 jumps (bit-exact): nothing
@@ -85,9 +87,7 @@ def test_save_restore_continue_and_reference_reads_it(sv, orc, tmp_path):
     import kangaroo_amd.hostlib as hl
     from tests.helpers import device_distances  # noqa: F401
 
-    start = 0x3C0FFEE00000000000000000
-    rp = 70
-    key = start + 0x2B5E6F7A8C9D0E1F23
+    key = start + key_off  # rp 125 = BASELINE configs[4]: maximal range, start 0, wild distances wrap mod n
     kxy = hl.pubkey(key)[1:]
     grid = (8, 128)
     n = grid[0] * grid[1] * 128
