@@ -257,9 +257,17 @@ KNG_DEV fe fe_mul_c32(const fe &a, const fe &b) {
 #ifndef KNG_MUL_IMPL
 #define KNG_MUL_IMPL 32
 #endif
+// a^2 with the 36-MAD squaring schedule (sqr_wide32) -- same 512-bit integer, same fold
+KNG_DEV fe fe_sqr_c32(const fe &a) {
+    uint32_t x[8], w[16];
+    fe_to32(x, a);
+    sqr_wide32(w, x);
+    return fe_fold32(w);
+}
+
 #if KNG_MUL_IMPL == 32
 KNG_DEV fe fe_mul(const fe &a, const fe &b) { return fe_mul_c32(a, b); }
-KNG_DEV fe fe_sqr(const fe &a) { return fe_mul_c32(a, a); }
+KNG_DEV fe fe_sqr(const fe &a) { return fe_sqr_c32(a); }
 #else
 KNG_DEV fe fe_mul(const fe &a, const fe &b) { return fe_mul_c64(a, b); }
 KNG_DEV fe fe_sqr(const fe &a) { return fe_sqr_c64(a); }
