@@ -104,6 +104,16 @@ def cpu_baseline(seconds: float = 20.0) -> dict:
             "sample": f"oracle/kng_oracle.c orc_walk, 1024 kangaroos x {steps} jumps, 1 thread"}
 
 
+def _kernel_name(eng) -> str:
+    """Name of the walk kernel the engine launches with its current options (as rocprofv3 prints it)."""
+    if eng.get_option("arith") != 32:
+        return "kng_walk29_kernel"
+    share, ds = eng.get_option("share"), eng.get_option("dsplit")
+    if share == 1:
+        return "kng_walk_dsplit_kernel" if ds else "kng_walk_kernel"
+    return f"kng_walk_share_kernel<{share}, {'true' if ds else 'false'}>"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,8 +257,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": {1: "kng_walk_kernel", 2: "kng_walk_share_kernel<2>", 3: "kng_walk_share_kernel<3>"}[eng.get_option("share")]
-            if eng.get_option("arith") == 32 else "kng_walk29_kernel",
+            "kernel": _kernel_name(eng),
             "kernel_ms": round(kms, 3),
             "alg_bytes_per_launch": jumps_per_step * ALG_BYTES_PER_JUMP,
         },

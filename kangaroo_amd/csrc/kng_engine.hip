@@ -75,6 +75,17 @@ KNG_DEV void st_fe(v16 *p01, v16 *p23, size_t i, const fe &v) {
     p01[i] = make_ulonglong2(v.v[0], v.v[1]);
     p23[i] = make_ulonglong2(v.v[2], v.v[3]);
 }
+// The distance plane holds the N low words followed by the N high words (two 8-byte planes): a walk whose
+// jump distances are far below 2^64 then only streams the low words (DSPLIT, see walk_body).
+KNG_DEV v16 ld_d(const v16 *d, size_t n, size_t i) {
+    const uint64_t *p = reinterpret_cast<const uint64_t *>(d);
+    return make_ulonglong2(p[i], p[n + i]);
+}
+KNG_DEV void st_d(v16 *d, size_t n, size_t i, const v16 &v) {
+    uint64_t *p = reinterpret_cast<uint64_t *>(d);
+    p[i] = v.x;
+    p[n + i] = v.y;
+}
 KNG_DEV fe lds_fe(const uint64_t *tab, int base, uint32_t j) {
     return fe{{tab[base + j], tab[base + 32 + j], tab[base + 64 + j], tab[base + 96 + j]}};
 }
@@ -108,8 +119,14 @@ KNG_DEV void emit_dp(bool is_dp, const fe &x, const v16 &d, uint64_t kidx, const
 //     i = 1/(acc*pb) ;  1/acc = i*pb ;  1/pb = i*acc          (3 extra multiplications per lane pair)
 // Two co-resident waves inverting side by side need ~2 x 64.5K SIMD cycles per jump of the pair; one wave
 // alone on the SIMD needs ~72K.  Results are unchanged (the canonical residue is the same).
-template <int SHARE>
+//
+// DSPLIT = true: the 128-bit distance only streams its LOW word through HBM.  d += jD[j] carries out of bit 64
+// with probability jD/2^64 (2^-23 per jump at an 80-bit range); the high word is read-modified-written on
+// that rare path and fetched when a distinguished point is emitted.  Saves 16 of 224 B/jump.  The host
+// enables it when every jump distance is below 2^50 (kng_set_params); results are identical.
+template <int SHARE, bool DSPLIT>
 KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
+    uint64_t *const dlo = reinterpret_cast<uint64_t *>(a.d), *const dhi = dlo + a.n_kang;
     const size_t L = a.lanes;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (SHARE == 1 && t >= L) return;
@@ -174,7 +191,7 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
         size_t idx = slot(0);
         fe cx = ld_fe(a.x01, a.x23, idx);
         fe cy = ld_fe(a.y01, a.y23, idx);
-        v16 cd = a.d[idx];
+        v16 cd = DSPLIT ? make_ulonglong2(dlo[idx], 0) : ld_d(a.d, a.n_kang, idx);
         fe nb = (G > 1) ? ld_fe(a.s01, a.s23, slot(1)) : fe_one();
 
         for (uint32_t k = 0; k < G; k++) {
@@ -186,7 +203,7 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
                 nidx = slot(k + 1);
                 nx = ld_fe(a.x01, a.x23, nidx);
                 ny = ld_fe(a.y01, a.y23, nidx);
-                nd = a.d[nidx];
+                nd = DSPLIT ? make_ulonglong2(dlo[nidx], 0) : ld_d(a.d, a.n_kang, nidx);
             }
             if (k + 2 < G) nnb = ld_fe(a.s01, a.s23, slot(k + 2));
 
@@ -208,18 +225,38 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
             const fe rx = fe_sub(fe_sub(p2, jx), cx);
             const fe ry = fe_sub(fe_mul(fe_sub(cx, rx), s), cy);
             // d += jD[j]: raw 128-bit add (GPUMath.h:119-121)
+            bool hi_known = !DSPLIT;
             {
-                const uint64_t jd0 = tab[JT_JD + j], jd1 = tab[JT_JD + 32 + j];
+                const uint64_t jd0 = tab[JT_JD + j];
                 unsigned long long c = 0;
                 cd.x = __builtin_addcll(cd.x, jd0, 0, &c);
-                cd.y = cd.y + jd1 + c;
+                if (DSPLIT) {
+                    if (__builtin_expect(c != 0, 0)) {
+                        KNG_RARE_PATH();
+                        cd.y = dhi[idx] + 1;
+                        dhi[idx] = cd.y;
+                        hi_known = true;
+                    }
+                } else {
+                    cd.y = cd.y + tab[JT_JD + 32 + j] + c;
+                }
             }
             st_fe(a.x01, a.x23, idx, rx);
             st_fe(a.y01, a.y23, idx, ry);
-            a.d[idx] = cd;
+            dlo[idx] = cd.x;
+            if (!DSPLIT) dhi[idx] = cd.y;
 
             // ---- distinguished point? (GPUCompute.h:96-105) ----
-            emit_dp((rx.v[3] & a.dp_mask) == 0, rx, cd, (uint64_t)idx, a);
+            {
+                const bool is_dp = (rx.v[3] & a.dp_mask) == 0;
+                if (DSPLIT && is_dp && !hi_known) {
+                    cd.y = dhi[idx];
+                    // consume the value inside the branch: a load left pending at the join would make hipcc
+                    // drain every outstanding memory operation (vmcnt(0)) at the top of the next iteration
+                    asm volatile("" ::"v"(cd.y));
+                }
+                emit_dp(is_dp, rx, cd, (uint64_t)idx, a);
+            }
 
             // ---- prefix product of the NEXT jump's dx, in this pass's order ----
             if (!last) {
@@ -241,16 +278,23 @@ __global__ void __launch_bounds__(256) kng_walk_kernel(const WalkArgs a) {
     __shared__ uint64_t tab[JT_WORDS];
     for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
     __syncthreads();
-    walk_body<1>(a, tab, nullptr);
+    walk_body<1, false>(a, tab, nullptr);
 }
 
-template <int SHARE>
+__global__ void __launch_bounds__(256) kng_walk_dsplit_kernel(const WalkArgs a) {
+    __shared__ uint64_t tab[JT_WORDS];
+    for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
+    __syncthreads();
+    walk_body<1, true>(a, tab, nullptr);
+}
+
+template <int SHARE, bool DSPLIT>
 __global__ void __launch_bounds__(256 * SHARE) kng_walk_share_kernel(const WalkArgs a) {
     __shared__ uint64_t tab[JT_WORDS];
     __shared__ v16 xch[512 * (SHARE - 1)];
     for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
     __syncthreads();
-    walk_body<SHARE>(a, tab, xch);
+    walk_body<SHARE, DSPLIT>(a, tab, xch);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -317,7 +361,7 @@ __global__ void __launch_bounds__(256) kng_herd_kernel(const HerdArgs a) {
         const v16 d = herd_distance(a.seed, idx, a.range_power);
         const uint64_t *b = a.base[idx & 1];
         const fe x{{b[0], b[1], b[2], b[3]}}, y{{b[4], b[5], b[6], b[7]}};
-        a.d[idx] = d;
+        st_d(a.d, a.n_kang, idx, d);
         st_fe(a.x01, a.x23, idx, x);
         st_fe(a.y01, a.y23, idx, y);
         fe qx, qy;
@@ -334,7 +378,7 @@ __global__ void __launch_bounds__(256) kng_herd_kernel(const HerdArgs a) {
         for (uint32_t k = 0; k < G; k++) {
             const size_t idx = slot(k);
             const fe cx = ld_fe(a.x01, a.x23, idx), cy = ld_fe(a.y01, a.y23, idx);
-            const v16 d = a.d[idx];
+            const v16 d = ld_d(a.d, a.n_kang, idx);
             fe qx, qy;
             const bool on = herd_addend(a, step, d, qx, qy);
             const fe dx = on ? fe_sub(cx, qx) : fe_one();
@@ -369,11 +413,11 @@ __global__ void __launch_bounds__(256) kng_herd_kernel(const HerdArgs a) {
 }
 
 // overwrite one kangaroo, stream-ordered (replaces the ten 8-byte copies of GPUEngine.cu:504-530)
-__global__ void kng_patch_kernel(v16 *x01, v16 *x23, v16 *y01, v16 *y23, v16 *d, uint64_t idx, fe x,
+__global__ void kng_patch_kernel(v16 *x01, v16 *x23, v16 *y01, v16 *y23, v16 *d, uint64_t n, uint64_t idx, fe x,
                                  fe y, v16 dd) {
     st_fe(x01, x23, idx, x);
     st_fe(y01, y23, idx, y);
-    d[idx] = dd;
+    st_d(d, n, idx, dd);
 }
 
 // walk policy "29": carry-free 9x29-bit limbs (kng_walk29.h)
@@ -391,10 +435,10 @@ __global__ void __launch_bounds__(256) kng_walk29_kernel(const Walk29Args a) {
     });
 }
 
-__global__ void kng_patch29_kernel(Planes29 x, Planes29 y, v16 *d, uint64_t idx, fe29 fx, fe29 fy, v16 dd) {
+__global__ void kng_patch29_kernel(Planes29 x, Planes29 y, v16 *d, uint64_t n, uint64_t idx, fe29 fx, fe29 fy, v16 dd) {
     st29(x, idx, fx);
     st29(y, idx, fy);
-    d[idx] = dd;
+    st_d(d, n, idx, dd);
 }
 
 // device self-test of the primitives (replaces the compiled-out check_gpu, GPUEngine.cu:43-92)
@@ -478,6 +522,9 @@ struct kng_engine {
     uint32_t lanes = 0;
     int cu_count = 0;
     // device memory
+    int dsplit = -1;       // distance plane: -1 = low-word streaming when every jump distance < 2^50, 0 = never, 1 = whenever the table allows (high words all zero)
+    bool dsplit_on = false; // decided by kng_set_params / the option
+    uint64_t jd_max = 0;    // largest low word of the jump distances, UINT64_MAX when a high word is set
     int share = 2;         // waves per SIMD (w, w+4, ..) of one 256*share-thread block that share one inversion per jump (policy 32)
     int arith = 32;        // walk policy: 32 = reference-exact lazy fold on saturated limbs, 29 = carry-free 9x29
     v16 *planes = nullptr; // 7 planes of n v16, then (policy 29) 3 planes of n dwords
@@ -506,6 +553,14 @@ struct kng_engine {
 };
 
 static inline v16 *plane(const kng_engine *h, int k) { return h->planes + (size_t)k * h->n; }
+// plane 4 = distances, stored as the N low words followed by the N high words
+static inline uint64_t *dplane(const kng_engine *h, int hi) { return reinterpret_cast<uint64_t *>(plane(h, 4)) + (hi ? h->n : 0); }
+// low-word streaming of the distances (walk_body DSPLIT): needs every high word of the table zero; automatic
+// only when a carry out of the low word is rare enough for its read-modify-write not to matter
+static void decide_dsplit(kng_engine *h) {
+    const bool possible = h->arith == 32 && h->jd_max != UINT64_MAX;
+    h->dsplit_on = possible && (h->dsplit == 1 || (h->dsplit == -1 && h->jd_max < (1ULL << 50)));
+}
 // policy 29: 16-byte planes 0..6 = xa xb ya yb d sa sb ; dword planes 0..2 = xc yc sc
 static inline uint32_t *plane_c(const kng_engine *h, int k) {
     return reinterpret_cast<uint32_t *>(h->planes + (size_t)7 * h->n) + (size_t)k * h->n;
@@ -719,9 +774,14 @@ int kng_set_option(kng_engine *h, const char *key, int64_t value) {
         if (value != 29 && value != 32) return fail(KNG_E_ARG, "arith must be 29 or 32");
         if (h->have_herd) return fail(KNG_E_STATE, "arith must be chosen before kng_set_kangaroos");
         h->arith = (int)value;
+        decide_dsplit(h);
     } else if (k == "steps") {
         if (value < 1 || value > 1 << 20) return fail(KNG_E_ARG, "steps out of range");
         h->nsteps = (uint32_t)value;
+    } else if (k == "dsplit") {
+        if (value < -1 || value > 1) return fail(KNG_E_ARG, "dsplit must be -1 (auto), 0 or 1");
+        h->dsplit = (int)value;
+        decide_dsplit(h);
     } else if (k == "share") {
         if (value < 1 || value > 3) return fail(KNG_E_ARG, "share must be 1, 2 or 3");
         h->share = (int)value;
@@ -740,6 +800,7 @@ int kng_get_option(const kng_engine *h, const char *key, int64_t *value) {
     else if (k == "arith") *value = h->arith;
     else if (k == "lanes") *value = h->lanes;
     else if (k == "share") *value = h->share;
+    else if (k == "dsplit") *value = h->dsplit_on ? 1 : 0;
     else if (k == "cu_count") *value = h->cu_count;
     else if (k == "waves_per_cu") *value = h->cu_count ? (int64_t)((h->lanes / 64 + h->cu_count - 1) / h->cu_count) : 0;
     else return fail(KNG_E_ARG, "unknown option '%s'", key);
@@ -759,6 +820,12 @@ int kng_set_params(kng_engine *h, uint64_t dp_mask, const uint64_t *jd, const ui
         tab[JT_JD + j] = jd[2 * j];
         tab[JT_JD + 32 + j] = jd[2 * j + 1];
     }
+    h->jd_max = 0;
+    for (int j = 0; j < KNG_NB_JUMP; j++) {
+        if (jd[2 * j + 1]) h->jd_max = UINT64_MAX;
+        else if (h->jd_max != UINT64_MAX && jd[2 * j] > h->jd_max) h->jd_max = jd[2 * j];
+    }
+    decide_dsplit(h);
     // policy 29: biased negations 2p - Jx, 2p - Jy as 29-bit limbs, limb-major; d as four dwords
     uint32_t tab29[JT29_WORDS];
     static const uint32_t P29x2[9] = {0x3FFFF85Eu, 0x3FFFFFEEu, 0x3FFFFFFEu, 0x3FFFFFFEu, 0x3FFFFFFEu,
@@ -816,6 +883,7 @@ int kng_set_kangaroos_range(kng_engine *h, uint64_t first, uint64_t count, const
     for (uint64_t c0 = first; c0 < n; c0 += C) {
         const size_t m = (size_t)((n - c0 < C) ? (n - c0) : C);
         v16 *st = h->h_stage;
+        uint64_t *sd = reinterpret_cast<uint64_t *>(st + 4 * C); // d low words [C], high words [C]
         if (h->arith == 29) {
             uint4 *sq = reinterpret_cast<uint4 *>(st);
             uint32_t *sc = reinterpret_cast<uint32_t *>(st + 5 * C); // xc[C] then yc[C]
@@ -833,7 +901,8 @@ int kng_set_kangaroos_range(kng_engine *h, uint64_t first, uint64_t count, const
                 sq[2 * C + i] = make_uint4(l[0], l[1], l[2], l[3]);
                 sq[3 * C + i] = make_uint4(l[4], l[5], l[6], l[7]);
                 sc[C + i] = l[8];
-                st[4 * C + i] = make_ulonglong2(pd[0], pd[1]);
+                sd[i] = pd[0];
+                sd[C + i] = pd[1];
             }
             for (int k = 0; k < 2; k++)
                 HIP_TRY(hipMemcpyAsync(plane_c(h, k) + c0, sc + (size_t)k * C, m * sizeof(uint32_t), hipMemcpyHostToDevice, h->walk));
@@ -844,11 +913,14 @@ int kng_set_kangaroos_range(kng_engine *h, uint64_t first, uint64_t count, const
                 st[1 * C + i] = make_ulonglong2(px[2], px[3]);
                 st[2 * C + i] = make_ulonglong2(py[0], py[1]);
                 st[3 * C + i] = make_ulonglong2(py[2], py[3]);
-                st[4 * C + i] = make_ulonglong2(pd[0], pd[1]);
+                sd[i] = pd[0];
+                sd[C + i] = pd[1];
             }
         }
-        for (int k = 0; k < 5; k++)
+        for (int k = 0; k < 4; k++)
             HIP_TRY(hipMemcpyAsync(plane(h, k) + c0, st + (size_t)k * C, m * sizeof(v16), hipMemcpyHostToDevice, h->walk));
+        for (int k = 0; k < 2; k++) // distance plane: N low words, then N high words
+            HIP_TRY(hipMemcpyAsync(dplane(h, k) + c0, sd + (size_t)k * C, m * sizeof(uint64_t), hipMemcpyHostToDevice, h->walk));
         HIP_TRY(hipStreamSynchronize(h->walk)); // staging buffer is reused
     }
     // the herd counts as loaded once its last kangaroo has been written (ranges are normally uploaded in order)
@@ -877,9 +949,12 @@ int kng_get_kangaroos_range(kng_engine *h, uint64_t first, uint64_t count, uint6
     for (uint64_t c0 = first; c0 < n; c0 += C) {
         const size_t m = (size_t)((n - c0 < C) ? (n - c0) : C);
         v16 *st = h->h_stage;
+        uint64_t *sd = reinterpret_cast<uint64_t *>(st + 4 * C); // d low words [C], high words [C]
         // stream-ordered behind an in-flight launch: returns the state that launch leaves
-        for (int k = 0; k < 5; k++)
+        for (int k = 0; k < 4; k++)
             HIP_TRY(hipMemcpyAsync(st + (size_t)k * C, plane(h, k) + c0, m * sizeof(v16), hipMemcpyDeviceToHost, h->walk));
+        for (int k = 0; k < 2; k++)
+            HIP_TRY(hipMemcpyAsync(sd + (size_t)k * C, dplane(h, k) + c0, m * sizeof(uint64_t), hipMemcpyDeviceToHost, h->walk));
         uint32_t *sc = reinterpret_cast<uint32_t *>(st + 5 * C);
         if (h->arith == 29)
             for (int k = 0; k < 2; k++)
@@ -894,15 +969,15 @@ int kng_get_kangaroos_range(kng_engine *h, uint64_t first, uint64_t count, uint6
                 const uint32_t ly[9] = {e.x, e.y, e.z, e.w, f.x, f.y, f.z, f.w, sc[C + i]};
                 host_canon256(lx, px); // x is canonical on the device already; y is only almost reduced
                 host_canon256(ly, py);
-                pd[0] = st[4 * C + i].x;
-                pd[1] = st[4 * C + i].y;
+                pd[0] = sd[i];
+                pd[1] = sd[C + i];
             }
         } else {
             for (size_t i = 0; i < m; i++) {
                 uint64_t *px = x + (c0 + i) * xs, *py = y + (c0 + i) * ys, *pd = d + (c0 + i) * ds;
                 px[0] = st[0 * C + i].x; px[1] = st[0 * C + i].y; px[2] = st[1 * C + i].x; px[3] = st[1 * C + i].y;
                 py[0] = st[2 * C + i].x; py[1] = st[2 * C + i].y; py[2] = st[3 * C + i].x; py[3] = st[3 * C + i].y;
-                pd[0] = st[4 * C + i].x; pd[1] = st[4 * C + i].y;
+                pd[0] = sd[i]; pd[1] = sd[C + i];
             }
         }
     }
@@ -953,12 +1028,12 @@ int kng_set_kangaroo(kng_engine *h, uint64_t kidx, const uint64_t x[4], const ui
         host_canon256(fx.l, cv);
         host_unpack29(cv, fx.l);
         host_unpack29(y, fy.l);
-        hipLaunchKernelGGL(kng_patch29_kernel, dim3(1), dim3(1), 0, h->walk, planes29(h, 0), planes29(h, 1), plane(h, 4), kidx,
+        hipLaunchKernelGGL(kng_patch29_kernel, dim3(1), dim3(1), 0, h->walk, planes29(h, 0), planes29(h, 1), plane(h, 4), h->n, kidx,
                            fx, fy, make_ulonglong2(d[0], d[1]));
     } else {
         fe fx{{x[0], x[1], x[2], x[3]}}, fy{{y[0], y[1], y[2], y[3]}};
         hipLaunchKernelGGL(kng_patch_kernel, dim3(1), dim3(1), 0, h->walk, plane(h, 0), plane(h, 1), plane(h, 2), plane(h, 3),
-                           plane(h, 4), kidx, fx, fy, make_ulonglong2(d[0], d[1]));
+                           plane(h, 4), h->n, kidx, fx, fy, make_ulonglong2(d[0], d[1]));
     }
     HIP_TRY(hipGetLastError());
     return KNG_OK;
@@ -1005,12 +1080,17 @@ int kng_launch(kng_engine *h) {
         b.nsteps = h->nsteps;
         hipLaunchKernelGGL(kng_walk29_kernel, dim3(blocks), dim3(h->block), 0, h->walk, b);
     } else {
-        if (h->share == 2)
-            hipLaunchKernelGGL(kng_walk_share_kernel<2>, dim3((h->lanes + 511) / 512), dim3(512), 0, h->walk, a);
-        else if (h->share == 3)
-            hipLaunchKernelGGL(kng_walk_share_kernel<3>, dim3((h->lanes + 767) / 768), dim3(768), 0, h->walk, a);
-        else
-            hipLaunchKernelGGL(kng_walk_kernel, dim3(blocks), dim3(h->block), 0, h->walk, a);
+        const bool ds = h->dsplit_on;
+        if (h->share == 2) {
+            if (ds) hipLaunchKernelGGL((kng_walk_share_kernel<2, true>), dim3((h->lanes + 511) / 512), dim3(512), 0, h->walk, a);
+            else hipLaunchKernelGGL((kng_walk_share_kernel<2, false>), dim3((h->lanes + 511) / 512), dim3(512), 0, h->walk, a);
+        } else if (h->share == 3) {
+            if (ds) hipLaunchKernelGGL((kng_walk_share_kernel<3, true>), dim3((h->lanes + 767) / 768), dim3(768), 0, h->walk, a);
+            else hipLaunchKernelGGL((kng_walk_share_kernel<3, false>), dim3((h->lanes + 767) / 768), dim3(768), 0, h->walk, a);
+        } else {
+            if (ds) hipLaunchKernelGGL(kng_walk_dsplit_kernel, dim3(blocks), dim3(h->block), 0, h->walk, a);
+            else hipLaunchKernelGGL(kng_walk_kernel, dim3(blocks), dim3(h->block), 0, h->walk, a);
+        }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev_stop[s], h->walk));

@@ -38,6 +38,16 @@ struct Walk29Args {
     uint64_t n_kang;
 };
 
+// distance plane: N low words followed by N high words (layout shared with the policy-32 kernels)
+KNG_DEV ulonglong2 ld_d29(const ulonglong2 *d, size_t n, size_t i) {
+    const uint64_t *p = reinterpret_cast<const uint64_t *>(d);
+    return make_ulonglong2(p[i], p[n + i]);
+}
+KNG_DEV void st_d29(ulonglong2 *d, size_t n, size_t i, const ulonglong2 &v) {
+    uint64_t *p = reinterpret_cast<uint64_t *>(d);
+    p[i] = v.x;
+    p[n + i] = v.y;
+}
 KNG_DEV fe29 ld29(const Planes29 &p, size_t i) {
     const uint4 a = p.a[i], b = p.b[i];
     const uint32_t c = p.c[i];
@@ -85,7 +95,7 @@ KNG_DEV void walk29_body(const Walk29Args &a, const uint32_t *tab, EmitFn emit) 
         size_t idx = slot(0);
         fe29 cx = ld29(a.x, idx);
         fe29 cy = ld29(a.y, idx);
-        ulonglong2 cd = a.d[idx];
+        ulonglong2 cd = ld_d29(a.d, a.n_kang, idx);
         fe29 nb = cx;
         if (G > 1) nb = ld29(a.s, slot(1));
 
@@ -98,7 +108,7 @@ KNG_DEV void walk29_body(const Walk29Args &a, const uint32_t *tab, EmitFn emit) 
                 nidx = slot(k + 1);
                 nx = ld29(a.x, nidx);
                 ny = ld29(a.y, nidx);
-                nd = a.d[nidx];
+                nd = ld_d29(a.d, a.n_kang, nidx);
             }
             if (k + 2 < G) nnb = ld29(a.s, slot(k + 2));
 
@@ -130,7 +140,7 @@ KNG_DEV void walk29_body(const Walk29Args &a, const uint32_t *tab, EmitFn emit) 
             }
             st29(a.x, idx, rx);
             st29(a.y, idx, ry);
-            a.d[idx] = cd;
+            st_d29(a.d, a.n_kang, idx, cd);
 
             const bool is_dp = (((rx.l[8] & a.m8) | (rx.l[7] & a.m7) | (rx.l[6] & a.m6)) == 0);
             emit(is_dp, rx, cd, (uint64_t)idx);

@@ -575,6 +575,61 @@ def test_ragged_groups_vs_oracle(kng, orc, grid, lanes, arith):
     eng.close()
 
 
+@pytest.mark.parametrize("share", [1, 2])
+def test_distance_low_word_streaming_vs_oracle(kng, orc, share):
+    """Option "dsplit": only the low word of the 128-bit distance streams through HBM; the high word is
+    read-modified-written when the add carries and fetched when a DP is emitted.  Forced on with jump distances
+    just below 2^64 so that about every third jump carries (automatic mode would refuse), start distances
+    straddling 2^64, dp 3: kangaroos, distances and DP records must still match the oracle bit for bit."""
+    grid = (4, 4)
+    n = grid[0] * grid[1] * 128
+    rp = 72
+    x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=4242)
+    _, jx, jy, _ = orc.jump_table(rp)
+    rng = np.random.default_rng(9)
+    jd = np.zeros((32, 2), np.uint64)
+    jd[:, 0] = rng.integers(1 << 61, (1 << 64) - 1, size=32, dtype=np.uint64)
+    d = np.zeros((n, 2), np.uint64)
+    d[:, 0] = rng.integers(0, (1 << 64) - 1, size=n, dtype=np.uint64)
+    d[:, 1] = rng.integers(0, 1 << 40, size=n, dtype=np.uint64)
+    d[::7, 1] = np.uint64((1 << 64) - 1)  # high word wraps too (raw 128-bit add, GPUMath.h:119-121)
+    mask = orc.dp_mask(3)
+    eng = kng.GPUEngine(grid[0], grid[1], 0, 1 << 17, share=share, group=8, dsplit=1)
+    eng.SetParams(mask, jd, jx, jy)
+    assert eng.get_option("dsplit") == 1
+    eng.SetKangaroos(x, y, d)
+    ox, oy, od = x.copy(), y.copy(), d.copy()
+    for _ in range(3):
+        eng.callKernel()
+        eng.wait()
+        got = eng.drain(raw=True)
+        want, total = orc.walk(ox, oy, od, 64, jd, jx, jy, mask, dp_cap=1 << 22)
+        key = lambda r: (int(r["kidx"]), tuple(int(v) for v in r["x"]), tuple(int(v) for v in r["d"]))  # noqa: E731
+        assert len(got) == total and sorted(map(key, got)) == sorted(map(key, want))
+        gx, gy, gd = eng.GetKangaroos(raw=True)
+        assert np.array_equal(gx, ox) and np.array_equal(gy, oy) and np.array_equal(gd, od)
+    eng.close()
+
+
+def test_distance_low_word_streaming_is_chosen_by_the_jump_table(kng, orc):
+    eng = kng.GPUEngine(2, 2, 0, 1 << 12)
+    for rp, want in ((72, 1), (98, 1), (100, 0), (125, 0)):  # jump distances < 2^(rp/2+1): auto below 2^50
+        jd, jx, jy, _ = orc.jump_table(rp)
+        eng.SetParams(orc.dp_mask(8), jd, jx, jy)
+        assert eng.get_option("dsplit") == want, rp
+    jd, jx, jy, _ = orc.jump_table(72)
+    jd = jd.copy()
+    jd[5, 1] = 1  # a high word in the table: never, even when forced
+    eng.set_option("dsplit", 1)
+    eng.SetParams(orc.dp_mask(8), jd, jx, jy)
+    assert eng.get_option("dsplit") == 0
+    eng.set_option("dsplit", 0)
+    jd, jx, jy, _ = orc.jump_table(72)
+    eng.SetParams(orc.dp_mask(8), jd, jx, jy)
+    assert eng.get_option("dsplit") == 0
+    eng.close()
+
+
 @pytest.mark.parametrize("arith", [32, 29])
 def test_ranged_set_get_of_the_herd(kng, arith):
     """kng_set_kangaroos_range / kng_get_kangaroos_range: the herd uploaded in uneven slices (crossing the 64 K

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--dp", type=int, default=14)
     ap.add_argument("--ariths", default="29,32")
     ap.add_argument("--shares", default="2", help="comma list of 1/2/3: waves per SIMD sharing one inversion")
+    ap.add_argument("--dsplit", type=int, default=-1, help="-1 auto / 0 / 1: low-word streaming of the distances")
     ap.add_argument("--lanes", default="", help="explicit lane counts (ragged groups); overrides --groups")
     a = ap.parse_args()
     gx, gy = (int(v) for v in a.grid.split(","))
@@ -44,7 +45,7 @@ def main():
     for ar, (gk, g), b, sh in ((ar, g, b, sh) for ar in (int(v) for v in a.ariths.split(",")) for g in glist
                                for b in (int(v) for v in a.blocks.split(",")) for sh in (int(v) for v in a.shares.split(","))):
         if True:
-            eng = k.GPUEngine(gx, gy, 0, 1 << 17, block=b, arith=ar, share=sh, **{gk: g})
+            eng = k.GPUEngine(gx, gy, 0, 1 << 17, block=b, arith=ar, share=sh, **({"dsplit": a.dsplit} if a.dsplit >= 0 else {}), **{gk: g})
             eng.SetParams(mask, jd, jx, jy)
             eng.SetKangaroos(x, y, d)
             eng.callKernel()
