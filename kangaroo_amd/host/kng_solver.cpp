@@ -87,7 +87,7 @@ struct Worker {
     std::mutex reset_m;
     std::vector<uint64_t> resets; // kangaroos to replace (same-herd collisions), filled by the consumers
     std::atomic<uint64_t> launches{0};
-    double kernel_ms_sum = 0; // GPU thread only; read after pause/stop or approximately for stats
+    std::atomic<uint64_t> kernel_us_sum{0}; // walk-kernel time of all launches, microseconds
     bool ended = false, paused = false; // guarded by kngs_solver::ctl_m
     uint64_t reset_seq = 0;
 };
@@ -247,7 +247,7 @@ void worker_main(kngs_solver *s, Worker *w) {
         if (kng_wait(w->eng, 0) != KNG_OK) return bail(std::string("kng_wait: ") + kng_last_error());
         float ms = 0;
         kng_last_kernel_ms(w->eng, &ms);
-        w->kernel_ms_sum += ms;
+        w->kernel_us_sum += (uint64_t)(ms * 1000.0f + 0.5f);
         const uint64_t done = ++w->launches;
         const bool last = s->cfg.max_launches && done >= s->cfg.max_launches;
         const bool go_on = !s->stop && !s->pause_req && !last;
@@ -568,13 +568,17 @@ int kngs_get_stats(const kngs_solver *s, kngs_stats *st) {
     std::memset(st, 0, sizeof *st);
     double kms = 0;
     int running = 0;
+    {
+        std::lock_guard<std::mutex> g(const_cast<kngs_solver *>(s)->ctl_m);
+        for (const Worker *w : s->workers)
+            if (!w->ended) running++;
+    }
     for (const Worker *w : s->workers) {
         const uint64_t l = w->launches.load();
         st->launches += l;
         st->jumps += l * w->n * KNG_NB_RUN;
         st->kangaroos += w->n;
-        kms += w->kernel_ms_sum;
-        if (!w->ended) running++;
+        kms += (double)w->kernel_us_sum.load() * 1e-3;
     }
     st->jumps += s->offset_count;
     st->dps = s->dps;
