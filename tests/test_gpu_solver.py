@@ -162,6 +162,17 @@ def test_reference_program_resumes_from_our_workfile(sv, tmp_path):
     assert "Fetch kangaroos" in out.stdout or "LoadWork" in out.stdout
 
 
+def test_solver_from_cpp(sv, tmp_path):
+    """The C ABI of the pipeline used from C++ (the reference's language): tests/cpp/test_solver.cpp."""
+    host = os.path.join(ROOT, "kangaroo_amd", "host")
+    lib = os.path.join(ROOT, "kangaroo_amd", "lib")
+    exe = str(tmp_path / "test_solver")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I", host, os.path.join(ROOT, "tests", "cpp", "test_solver.cpp"),
+                           "-o", exe, "-L", lib, "-lkangaroo_host", "-lkangaroo_hip", "-Wl,-rpath," + lib, "-lpthread"])
+    out = subprocess.run([exe, str(tmp_path / "cpp.work")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "CPP solver ok: key 0x378ABDEC51BC5D" in out.stdout, out.stdout[-1500:] + out.stderr[-500:]
+
+
 def test_pipeline_keeps_up_with_the_kernel_at_auto_dp(sv):
     """SURVEY 8(d) config 3 (80-bit range, 2^23 kangaroos, auto DP 14: about 33k DPs per 27 ms launch).  The
     reference's host loop (HashTable::Add under one mutex between launches) limits its own program to ~60 % of the
