@@ -663,7 +663,7 @@ static void choose_geometry(kng_engine *h) {
     // kept busy.  Default: the largest group that still leaves >= 2 waves per SIMD.
     if (h->group == 0) {
         const uint64_t want_lanes = (uint64_t)h->cu_count * 4 * 64 * 2;
-        uint32_t g = KNG_GRP_SIZE;
+        uint32_t g = 4 * KNG_GRP_SIZE; // herds beyond 2^24 keep 2 waves/SIMD with even longer batches
         while (g > 16 && h->n / g < want_lanes) g >>= 1;
         h->group = g;
     }
