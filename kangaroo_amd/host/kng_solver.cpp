@@ -143,7 +143,7 @@ void set_error(kngs_solver *s, const std::string &msg) {
 }
 
 // Kangaroo::CheckKey (Kangaroo.cpp:233-268) for the four sign combinations of (Td, Wd)
-bool resolve(kngs_solver *s, const uint64_t td[4], const uint64_t wd[4], uint64_t priv[4]) {
+bool resolve(const kngs_solver *s, const uint64_t td[4], const uint64_t wd[4], uint64_t priv[4]) {
     for (int type = 0; type < 4; type++) {
         uint64_t d1[4], d2[4], pk[4], px[4], py[4];
         if (type & 1) kngh_sub_order(ZERO4, td, d1); else std::memcpy(d1, td, 32);
@@ -593,6 +593,11 @@ int kngs_get_stats(const kngs_solver *s, kngs_stats *st) {
     st->solved = s->solved ? 1 : 0;
     st->running = s->started && !s->joined ? running : 0;
     return 0;
+}
+
+int kngs_collision_key(const kngs_solver *s, const uint64_t tame_d[4], const uint64_t wild_d[4], uint64_t priv[4]) {
+    if (!s || !tame_d || !wild_d || !priv) return fail("null argument");
+    return resolve(s, tame_d, wild_d, priv) ? 1 : 0;
 }
 
 int kngs_save(kngs_solver *s, const char *path, int with_kangaroos) {

@@ -77,6 +77,10 @@ int kngs_get_stats(const kngs_solver *s, kngs_stats *st);
 /* save a HEADW work file at the next launch boundary (GPUs pause, resume afterwards); with_kangaroos != 0
  * appends every herd (96 B per kangaroo, GPU order) like -ws.  Works while running and after kngs_stop. */
 int kngs_save(kngs_solver *s, const char *path, int with_kangaroos);
+/* Kangaroo::CollisionCheck + CheckKey (Kangaroo.cpp:233-329) as a pure function of the configuration: given the
+ * true distances (mod n) of a tame and a wild kangaroo standing on the same point, try the reference's four sign
+ * combinations and return the private key (1) or 0 when none reproduces the public key.  No GPU needed. */
+int kngs_collision_key(const kngs_solver *s, const uint64_t tame_d[4], const uint64_t wild_d[4], uint64_t priv[4]);
 const char *kngs_last_error(void);
 
 #ifdef __cplusplus

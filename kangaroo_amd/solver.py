@@ -86,6 +86,7 @@ def _lib() -> C.CDLL:
         L.kngs_result.argtypes = [C.c_void_p, _U64P]
         L.kngs_get_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
         L.kngs_save.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.kngs_collision_key.argtypes = [C.c_void_p, _U64P, _U64P, _U64P]
         L.kngs_last_error.restype = C.c_char_p
         _bound = True
     return L
@@ -241,6 +242,13 @@ class Solver:
         st = _Stats()
         self._check(self._L.kngs_get_stats(self._h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in _Stats._fields_}
+
+    def collision_key(self, tame_d: int, wild_d: int):
+        """CollisionCheck/CheckKey (Kangaroo.cpp:233-329): the private key from the true distances (mod n) of a tame
+        and a wild kangaroo on the same point, or None when the collision does not resolve."""
+        out = np.zeros(4, np.uint64)
+        rc = self._check(self._L.kngs_collision_key(self._h, limbs(tame_d), limbs(wild_d), out))
+        return to_int(out) if rc == 1 else None
 
     def save(self, path: str, with_kangaroos: bool = True):
         self._check(self._L.kngs_save(self._h, path.encode(), 1 if with_kangaroos else 0))
