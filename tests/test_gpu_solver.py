@@ -162,6 +162,43 @@ def test_reference_program_resumes_from_our_workfile(sv, tmp_path):
     assert "Fetch kangaroos" in out.stdout or "LoadWork" in out.stdout
 
 
+def test_saves_while_running_are_consistent_snapshots(sv, tmp_path):
+    """kngs_save parks the GPU threads at a launch boundary, waits for the DP queues to drain, writes, resumes.
+    Repeated saves of a RUNNING two-engine solver must each be a consistent snapshot: the header count is a whole
+    number of launches, the table holds exactly the DPs received minus the rejected ones, later snapshots extend
+    earlier ones, and the reference's -wcheck accepts the last one."""
+    import kangaroo_amd.hostlib as hl
+
+    start = 0x42000000000000000000
+    rp = 76
+    kxy = hl.pubkey(start + 0x5A5A5A5A5A5A5A5A5A5)[1:]
+    grid = (16, 128)
+    n = grid[0] * grid[1] * 128
+    s = sv.Solver(start, start + (1 << rp) - 1, kxy, gpus=(0, 0), grid=grid, dp=12, seed=31)
+    s.start()
+    prev_count, prev_items = 0, 0
+    for i in range(4):
+        assert s.wait(0.25) == 0
+        path = str(tmp_path / f"snap{i}.work")
+        s.save(path, with_kangaroos=(i == 3))
+        t = sv.DpTable()
+        h, nk, kang = sv.read_workfile(path, t, with_kangaroos=False)
+        assert h["count"] % (n * 64) == 0 and h["count"] > prev_count, (i, h["count"])
+        assert t.count() > prev_items
+        assert nk == (2 * n if i == 3 else 0)
+        prev_count, prev_items = h["count"], t.count()
+        t.close()
+    assert s.wait(0.2) == 0  # still running after the saves
+    s.stop()
+    st = s.stats()
+    assert st["jumps"] >= prev_count and st["wrong_collisions"] == 0 and st["dps_lost"] == 0
+    assert st["table_items"] == st["dps"] - st["same_herd"]
+    s.close()
+    if os.path.exists(REF_CPU):
+        chk = subprocess.run([REF_CPU, "-t", "8", "-wcheck", path], capture_output=True, text=True, timeout=300).stdout
+        assert "[100.000% OK]" in chk, chk[-1500:]
+
+
 def test_solver_from_cpp(sv, tmp_path):
     """The C ABI of the pipeline used from C++ (the reference's language): tests/cpp/test_solver.cpp."""
     host = os.path.join(ROOT, "kangaroo_amd", "host")
