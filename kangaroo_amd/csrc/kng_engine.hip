@@ -162,8 +162,8 @@ KNG_DEV void emit_dp(bool is_dp, const fe &x, const v16 &d, uint64_t kidx, const
 // .. of the block) share ONE inversion per jump.  Waves w+4.. park their lane products in LDS and wait at
 // the barrier; wave w inverts the product of all chains and hands the individual inverses back, e.g.
 //     i = 1/(acc*pb) ;  1/acc = i*pb ;  1/pb = i*acc          (3 extra multiplications per lane pair)
-// Two co-resident waves inverting side by side need ~2 x 64.5K SIMD cycles per jump of the pair; one wave
-// alone on the SIMD needs ~72K.  Results are unchanged (the canonical residue is the same).
+// Two co-resident waves inverting side by side need ~2 x 55K SIMD cycles per jump of the pair; one wave
+// alone on the SIMD needs ~61K.  Results are unchanged (the canonical residue is the same).
 //
 // DSPLIT = true: the 128-bit distance only streams its LOW word through HBM.  d += jD[j] carries out of bit 64
 // with probability jD/2^64 (2^-23 per jump at an 80-bit range); the high word is read-modified-written on
