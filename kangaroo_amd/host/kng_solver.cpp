@@ -512,7 +512,9 @@ int kngs_start(kngs_solver *s) {
         kngw_close(s->herd_file);
         s->herd_file = nullptr;
     }
-    int nc = cfg.consumers > 0 ? cfg.consumers : (cfg.n_gpus >= 4 ? 4 : (cfg.n_gpus >= 2 ? 2 : 1));
+    // one table thread sustains several million inserts per second; a GPU emits ~1.3 M DPs/s at the suggested DP
+    // size alone and proportionally more when the population grows (the suggestion shrinks with log2 of it)
+    int nc = cfg.consumers > 0 ? cfg.consumers : (cfg.n_gpus == 1 ? 1 : (2 * cfg.n_gpus > 16 ? 16 : 2 * cfg.n_gpus));
     for (int c = 0; c < nc; c++) s->consumers.push_back(new Consumer());
     s->t_start = Clock::now();
     s->started = true;
