@@ -16,7 +16,7 @@ if [ -x oracle/_ref/kangaroo_hip ]; then
 fi
 echo "== bench"; python bench.py 2> $OUT/${TAG}_bench.err | tee $OUT/${TAG}_bench.json; tail -3 $OUT/${TAG}_bench.err
 echo "== rocprofv3 kernel trace"
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o kt -- python $OLDPWD/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pipeline > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o kt -- python $OLDPWD/bench.py --no-cpu-baseline --no-pipeline > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err)
 find $OUT/${TAG}_prof -name "*kernel_stats*" | head -3
 for f in $(find $OUT/${TAG}_prof -name "*kernel_stats.csv"); do cp $f $OUT/${TAG}_kernel_stats.csv; done
 cat $OUT/${TAG}_kernel_stats.csv 2>/dev/null | head -8
