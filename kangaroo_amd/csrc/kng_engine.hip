@@ -682,7 +682,8 @@ int kng_device_info(int dev, char *name, size_t name_cap, int *cu_count, uint64_
     if (dev < 0 || dev >= kng_device_count()) return fail(KNG_E_NODEVICE, "invalid device %d", dev);
     hipDeviceProp_t p;
     HIP_TRY(hipGetDeviceProperties(&p, dev));
-    if (name && name_cap) snprintf(name, name_cap, "%s", p.name);
+    // the marketing name comes from libdrm's amdgpu.ids and is empty on boxes that lack the file
+    if (name && name_cap) snprintf(name, name_cap, "%s", p.name[0] ? p.name : p.gcnArchName);
     if (arch && arch_cap) snprintf(arch, arch_cap, "%s", p.gcnArchName);
     if (cu_count) *cu_count = p.multiProcessorCount;
     if (mem_bytes) *mem_bytes = (uint64_t)p.totalGlobalMem;
