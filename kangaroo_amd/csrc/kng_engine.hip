@@ -555,6 +555,17 @@ static int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(KNG_E_HIP, "%s: %s", #expr, hipGetErrorString(e_));         \
     } while (0)
 
+// temporary device allocation released on every exit path of the function that owns it
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+    template <typename T>
+    T *as() const { return static_cast<T *>(p); }
+};
+
 struct kng_engine {
     int dev = 0;
     int grid_x = 0, grid_y = 0;
@@ -1038,14 +1049,14 @@ int kng_build_herd(kng_engine *h, int range_power, uint64_t seed, const uint64_t
     if (h->arith != 32) return fail(KNG_E_STATE, "device herd creation needs walk policy arith=32");
     if (h->outstanding) return fail(KNG_E_STATE, "a launch is outstanding");
     HIP_TRY(hipSetDevice(h->dev));
-    uint64_t *dtab = nullptr;
+    DevBuf dtab;
     const size_t tbytes = (size_t)windows * 256 * 8 * sizeof(uint64_t);
-    HIP_TRY(hipMalloc((void **)&dtab, tbytes));
-    HIP_TRY(hipMemcpyAsync(dtab, table, tbytes, hipMemcpyHostToDevice, h->walk));
+    HIP_TRY(dtab.alloc(tbytes));
+    HIP_TRY(hipMemcpyAsync(dtab.p, table, tbytes, hipMemcpyHostToDevice, h->walk));
     HerdArgs a;
     a.x01 = plane(h, 0); a.x23 = plane(h, 1); a.y01 = plane(h, 2); a.y23 = plane(h, 3);
     a.d = plane(h, 4); a.s01 = plane(h, 5); a.s23 = plane(h, 6);
-    a.table = dtab;
+    a.table = dtab.as<uint64_t>();
     memcpy(a.base[0], base_tame, 64);
     memcpy(a.base[1], base_wild, 64);
     memcpy(a.fin, final_add, 64);
@@ -1058,7 +1069,6 @@ int kng_build_herd(kng_engine *h, int range_power, uint64_t seed, const uint64_t
     hipLaunchKernelGGL(kng_herd_kernel, dim3(blocks), dim3(h->block), 0, h->walk, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->walk));
-    (void)hipFree(dtab);
     h->have_herd = true;
     return KNG_OK;
 }
@@ -1229,19 +1239,17 @@ int kng_test_fieldop(int dev, int op, const uint64_t *a, const uint64_t *b, uint
     if (n == 0) return KNG_OK;
     if (dev < 0 || dev >= kng_device_count()) return fail(KNG_E_NODEVICE, "invalid device %d (no CPU fallback)", dev);
     HIP_TRY(hipSetDevice(dev));
-    uint64_t *da = nullptr, *db = nullptr, *dr = nullptr;
+    DevBuf da, db, dr;
     const size_t bytes = (size_t)n * 32;
-    HIP_TRY(hipMalloc((void **)&da, bytes));
-    HIP_TRY(hipMalloc((void **)&db, bytes));
-    HIP_TRY(hipMalloc((void **)&dr, bytes));
-    HIP_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(kng_fieldop_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, op, da, db, dr, n);
+    HIP_TRY(da.alloc(bytes));
+    HIP_TRY(db.alloc(bytes));
+    HIP_TRY(dr.alloc(bytes));
+    HIP_TRY(hipMemcpy(da.p, a, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db.p, b, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kng_fieldop_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, op, da.as<uint64_t>(), db.as<uint64_t>(),
+                       dr.as<uint64_t>(), n);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(r, dr, bytes, hipMemcpyDeviceToHost));
-    (void)hipFree(da);
-    (void)hipFree(db);
-    (void)hipFree(dr);
+    HIP_TRY(hipMemcpy(r, dr.p, bytes, hipMemcpyDeviceToHost));
     return KNG_OK;
 }
 
