@@ -717,11 +717,13 @@ static void choose_geometry(kng_engine *h) {
     // lanes L = n / group.  The per-lane batch amortises one modular inversion, so bigger is
     // cheaper -- but one wave can only issue a VALU instruction every ~5 cycles on gfx950
     // (profiles/r01_clock_probe.txt), so every SIMD needs at least two resident waves to be
-    // kept busy.  Default: the largest group that still leaves >= 2 waves per SIMD.
+    // kept busy.  Default: the largest group that still leaves >= 2 waves per SIMD; herds too small to
+    // fill the chip shrink the batch down to 1 -- spreading over idle SIMDs beats amortising the inversion
+    // (2^16 kangaroos: 0.67 -> 2.2 GK/s, 2^20: 10.5 -> 15.0 GK/s, profiles/r01_herd_size_sweep.txt).
     if (h->group == 0) {
         const uint64_t want_lanes = (uint64_t)h->cu_count * 4 * 64 * 2;
         uint32_t g = 4 * KNG_GRP_SIZE; // herds beyond 2^24 keep 2 waves/SIMD with even longer batches
-        while (g > 16 && h->n / g < want_lanes) g >>= 1;
+        while (g > 1 && h->n / g < want_lanes) g >>= 1;
         h->group = g;
     }
     while (h->group > 1 && (h->n % h->group)) h->group >>= 1;
