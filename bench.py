@@ -106,8 +106,6 @@ def cpu_baseline(seconds: float = 20.0) -> dict:
 
 def _kernel_name(eng) -> str:
     """Name of the walk kernel the engine launches with its current options (as rocprofv3 prints it)."""
-    if eng.get_option("arith") != 32:
-        return "kng_walk29_kernel"
     share, ds = eng.get_option("share"), eng.get_option("dsplit")
     if share == 1:
         return "kng_walk_dsplit_kernel" if ds else "kng_walk_kernel"

@@ -139,9 +139,6 @@ int kng_last_kernel_ms(const kng_engine *h, float *ms);
  *            distance given to kng_set_params is below 2^50 (the high word is then updated on the rare carry);
  *            0 = never, 1 = whenever the table allows it (all high words zero).  Reads back 0/1 = in effect.
  *   "steps"  jumps per launch (default KNG_NB_RUN; only tests change it)
- *   "arith"  walk arithmetic policy: 32 = saturated 32-bit limbs with the reference's exact lazy fold
- *            (GPUMath.h:840-856; default), 29 = carry-free 9x29-bit limbs (same speed on MI355X: fewer
- *            instructions but more multiplies, and the chip is power-limited -- see DESIGN.md)
  * kng_get_option reads them back (also "lanes", "waves_per_cu"). */
 int kng_set_option(kng_engine *h, const char *key, int64_t value);
 int kng_get_option(const kng_engine *h, const char *key, int64_t *value);
@@ -152,19 +149,6 @@ int kng_get_option(const kng_engine *h, const char *key, int64_t *value);
 #define KNG_OP_MODSQR 1 /* GPUMath.h:909-1019 */
 #define KNG_OP_MODSUB 2 /* GPUMath.h:476-494  */
 #define KNG_OP_MODINV 3 /* GPUMath.h:700-803  */
-/* the carry-free 9x29-bit arithmetic of walk policy 29 (kng_field29.h): canonical results */
-#define KNG_OP_MUL29 4 /* a*b mod p                                  */
-#define KNG_OP_SUB29 5 /* a-b mod p through the biased lazy form      */
-#define KNG_OP_RX29 6  /* a^2 - b - a mod p   (shape of rx)           */
-#define KNG_OP_RY29 7  /* (a-b)*a - b mod p   (shape of ry)           */
-#define KNG_OP_INV29 8 /* a^-1 mod p, 0 -> 0                          */
-#define KNG_OP_JUMP29 9 /* one complete jump in the kernel's op sequence: P=(a, b-a mod p), J=(b, b^1 with bit 255 cleared);
-                           returns rx - ry mod p; the next five return its intermediates */
-#define KNG_OP_JUMP29_INV 10 /* 1/(a-b)        */
-#define KNG_OP_JUMP29_S 11   /* the slope      */
-#define KNG_OP_JUMP29_RX 12  /* new x          */
-#define KNG_OP_JUMP29_RY 13  /* new y          */
-#define KNG_OP_JUMP29_DX 14  /* a-b            */
 int kng_test_fieldop(int dev, int op, const uint64_t *a, const uint64_t *b, uint64_t *r, uint64_t n);
 
 /* ---- pinned host memory: AllocatePinnedMemory/FreePinnedMemory, GPUEngine.cu:311-327 ---------- */

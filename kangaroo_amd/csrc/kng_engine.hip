@@ -32,7 +32,6 @@
 #include "../../include/kangaroo_hip.h"
 #include "kng_field.h"
 #include "kng_modinv.h"
-#include "kng_walk29.h"
 
 using namespace kng;
 
@@ -465,27 +464,6 @@ __global__ void kng_patch_kernel(v16 *x01, v16 *x23, v16 *y01, v16 *y23, v16 *d,
     st_d(d, n, idx, dd);
 }
 
-// walk policy "29": carry-free 9x29-bit limbs (kng_walk29.h)
-__global__ void __launch_bounds__(256) kng_walk29_kernel(const Walk29Args a) {
-    __shared__ uint32_t tab[JT29_WORDS];
-    for (uint32_t i = threadIdx.x; i < JT29_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
-    __syncthreads();
-    WalkArgs dpa;
-    dpa.dp_count = a.dp_count;
-    dpa.dp_items = reinterpret_cast<DpRecord *>(a.dp_items);
-    dpa.max_found = a.max_found;
-    walk29_body(a, tab, [&](bool is_dp, const fe29 &x, const ulonglong2 &d, uint64_t kidx) {
-        // the 256-bit form of x is only needed for the few lanes that found a DP
-        if (__ballot(is_dp) != 0) emit_dp(is_dp, fe29_pack(x), d, kidx, dpa);
-    });
-}
-
-__global__ void kng_patch29_kernel(Planes29 x, Planes29 y, v16 *d, uint64_t n, uint64_t idx, fe29 fx, fe29 fy, v16 dd) {
-    st29(x, idx, fx);
-    st29(y, idx, fy);
-    st_d(d, n, idx, dd);
-}
-
 // device self-test of the primitives (replaces the compiled-out check_gpu, GPUEngine.cu:43-92)
 __global__ void kng_fieldop_kernel(int op, const uint64_t *a, const uint64_t *b, uint64_t *r, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -498,37 +476,7 @@ __global__ void kng_fieldop_kernel(int op, const uint64_t *a, const uint64_t *b,
     case KNG_OP_MODSQR: z = fe_sqr(x); break;
     case KNG_OP_MODSUB: z = fe_sub(x, y); break;
     case KNG_OP_MODINV: z = fe_inv(x); break;
-    case KNG_OP_MUL29: z = fe29_pack(fe29_canon(fe29_mul(fe29_unpack(x), fe29_unpack(y)))); break;
-    case KNG_OP_SUB29: z = fe29_pack(fe29_canon(fe29_add(fe29_unpack(x), fe29_neg2p(fe29_unpack(y))))); break;
-    case KNG_OP_RX29: { // x^2 - y - x : the shape of rx = s^2 - Jx - px
-        const fe29 ux = fe29_unpack(x), uy = fe29_unpack(y);
-        z = fe29_pack(fe29_canon(fe29_add(fe29_add(fe29_sqr(ux), fe29_neg2p(uy)), fe29_neg2p(ux))));
-        break;
-    }
-    case KNG_OP_RY29: { // (x - y)*x - y through the lazy/norm path : the shape of ry
-        const fe29 ux = fe29_unpack(x), uy = fe29_unpack(y);
-        z = fe29_pack(fe29_canon(fe29_norm(fe29_sub2p(fe29_mul(fe29_sub2p(ux, uy), ux), uy))));
-        break;
-    }
-    case KNG_OP_INV29: z = fe29_pack(fe29_inv(fe29_unpack(x))); break;
-    default: { // KNG_OP_JUMP29: x-coordinate of (a, a^3+7 is NOT required) + J with J = (b, b+1): the exact kernel sequence
-        const fe29 cx = fe29_unpack(x), cy = fe29_unpack(fe_sub(y, x)), jx = fe29_unpack(y);
-        const fe29 jy = fe29_unpack(fe_canon(fe{{y.v[0] ^ 1, y.v[1], y.v[2], y.v[3] & 0x7FFFFFFFFFFFFFFFULL}}));
-        const fe29 njx = fe29_neg2p(jx), njy = fe29_neg2p(jy);
-        const fe29 dx = fe29_add(cx, njx);
-        const fe29 inv = fe29_inv(fe29_norm(dx));
-        const fe29 s = fe29_mul(fe29_add(cy, njy), inv);
-        const fe29 rx = fe29_canon(fe29_add(fe29_add(fe29_sqr(s), njx), fe29_neg2p(cx)));
-        const fe29 m = fe29_mul(fe29_sub2p(cx, rx), s);
-        const fe29 ry = fe29_norm(fe29_sub2p(m, cy));
-        z = fe_sub(fe29_pack(rx), fe29_pack(fe29_canon(ry))); // rx - ry mod p (reference-exact sub): one number out
-        if (op == KNG_OP_JUMP29_INV) z = fe29_pack(fe29_canon(inv));
-        if (op == KNG_OP_JUMP29_S) z = fe29_pack(fe29_canon(s));
-        if (op == KNG_OP_JUMP29_RX) z = fe29_pack(rx);
-        if (op == KNG_OP_JUMP29_RY) z = fe29_pack(fe29_canon(ry));
-        if (op == KNG_OP_JUMP29_DX) z = fe29_pack(fe29_canon(dx));
-        break;
-    }
+    default: z = fe_zero(); break;
     }
     for (int k = 0; k < 4; k++) r[4 * i + k] = z.v[k];
 }
@@ -582,10 +530,7 @@ struct kng_engine {
     bool dsplit_on = false; // decided by kng_set_params / the option
     uint64_t jd_max = 0;    // largest low word of the jump distances, UINT64_MAX when a high word is set
     int share = 2;         // waves per SIMD (w, w+4, ..) of one 256*share-thread block that share one inversion per jump (policy 32)
-    int arith = 32;        // walk policy: 32 = reference-exact lazy fold on saturated limbs, 29 = carry-free 9x29
-    v16 *planes = nullptr; // 7 planes of n v16, then (policy 29) 3 planes of n dwords
-    uint32_t *jtab29 = nullptr;
-    uint32_t m8 = 0, m7 = 0, m6 = 0;
+    v16 *planes = nullptr; // 7 planes of n v16
     uint64_t *jtab = nullptr;
     uint32_t *dp_count[2] = {nullptr, nullptr};
     DpRecord *dp_items[2] = {nullptr, nullptr};
@@ -614,69 +559,9 @@ static inline uint64_t *dplane(const kng_engine *h, int hi) { return reinterpret
 // low-word streaming of the distances (walk_body DSPLIT): needs every high word of the table zero; automatic
 // only when a carry out of the low word is rare enough for its read-modify-write not to matter
 static void decide_dsplit(kng_engine *h) {
-    const bool possible = h->arith == 32 && h->jd_max != UINT64_MAX;
+    const bool possible = h->jd_max != UINT64_MAX;
     h->dsplit_on = possible && (h->dsplit == 1 || (h->dsplit == -1 && h->jd_max < (1ULL << 50)));
 }
-// policy 29: 16-byte planes 0..6 = xa xb ya yb d sa sb ; dword planes 0..2 = xc yc sc
-static inline uint32_t *plane_c(const kng_engine *h, int k) {
-    return reinterpret_cast<uint32_t *>(h->planes + (size_t)7 * h->n) + (size_t)k * h->n;
-}
-static inline Planes29 planes29(const kng_engine *h, int which) { // 0 = x, 1 = y, 2 = s
-    static const int pa[3] = {0, 2, 5};
-    Planes29 p;
-    p.a = reinterpret_cast<uint4 *>(plane(h, pa[which]));
-    p.b = reinterpret_cast<uint4 *>(plane(h, pa[which] + 1));
-    p.c = plane_c(h, which);
-    return p;
-}
-
-// ---- host-side conversions for policy 29 ----
-static void host_unpack29(const uint64_t v[4], uint32_t l[9]) {
-    for (int i = 0; i < 9; i++) {
-        const int bit = 29 * i, w = bit / 64, sh = bit % 64;
-        uint64_t x = v[w] >> sh;
-        if (sh > 35 && w + 1 < 4) x |= v[w + 1] << (64 - sh);
-        l[i] = (uint32_t)x & 0x1FFFFFFFu;
-    }
-}
-// limbs (any almost-reduced element: value < 2^261) -> canonical 256-bit words
-static void host_canon256(const uint32_t l[9], uint64_t out[4]) {
-    typedef unsigned __int128 u128;
-    uint64_t w[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < 9; i++) { // w += l[i] << (29 i)
-        const int bit = 29 * i, k = bit / 64, sh = bit % 64;
-        u128 add = (u128)l[i] << sh;
-        u128 c = (u128)w[k] + (uint64_t)add;
-        w[k] = (uint64_t)c;
-        c = (c >> 64) + (uint64_t)(add >> 64);
-        for (int m = k + 1; m < 5 && c; m++) {
-            c += w[m];
-            w[m] = (uint64_t)c;
-            c >>= 64;
-        }
-    }
-    const uint64_t K = 0x1000003D1ULL;
-    while (w[4]) { // fold 2^256 = K
-        u128 c = (u128)w[4] * K;
-        w[4] = 0;
-        for (int m = 0; m < 5; m++) {
-            c += w[m];
-            w[m] = (uint64_t)c;
-            c >>= 64;
-        }
-    }
-    // conditional subtraction of p: value >= p <=> value + K >= 2^256
-    uint64_t t[4];
-    u128 c = (u128)w[0] + K;
-    t[0] = (uint64_t)c;
-    for (int m = 1; m < 4; m++) {
-        c = (c >> 64) + w[m];
-        t[m] = (uint64_t)c;
-    }
-    const bool ge = (uint64_t)(c >> 64) != 0;
-    for (int m = 0; m < 4; m++) out[m] = ge ? t[m] : w[m];
-}
-
 extern "C" {
 
 const char *kng_last_error(void) { return g_err.c_str(); }
@@ -756,11 +641,10 @@ int kng_create(int dev, int grid_x, int grid_y, uint32_t max_found, kng_engine *
     };
     hipError_t e;
     const size_t plane_bytes = (size_t)h->n * sizeof(v16);
-    const size_t state_bytes = 7 * plane_bytes + 3 * (size_t)h->n * sizeof(uint32_t);
+    const size_t state_bytes = 7 * plane_bytes;
     if ((e = hipMalloc((void **)&h->planes, state_bytes)) != hipSuccess)
         return bail(fail(KNG_E_ALLOC, "herd state (%zu bytes): %s", state_bytes, hipGetErrorString(e)));
     if ((e = hipMalloc((void **)&h->jtab, JT_WORDS * 8)) != hipSuccess) return bail(fail(KNG_E_ALLOC, "jump table: %s", hipGetErrorString(e)));
-    if ((e = hipMalloc((void **)&h->jtab29, JT29_WORDS * 4)) != hipSuccess) return bail(fail(KNG_E_ALLOC, "jump table: %s", hipGetErrorString(e)));
     for (int s = 0; s < 2; s++) {
         if ((e = hipMalloc((void **)&h->dp_count[s], 64)) != hipSuccess) return bail(fail(KNG_E_ALLOC, "dp counter: %s", hipGetErrorString(e)));
         if ((e = hipMalloc((void **)&h->dp_items[s], (size_t)max_found * sizeof(DpRecord))) != hipSuccess)
@@ -782,7 +666,7 @@ int kng_create(int dev, int grid_x, int grid_y, uint32_t max_found, kng_engine *
     if (hipStreamCreateWithFlags(&h->walk, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(KNG_E_HIP, "stream creation failed"));
-    h->bytes = state_bytes + JT_WORDS * 8 + JT29_WORDS * 4 + 2 * (64 + (uint64_t)max_found * sizeof(DpRecord));
+    h->bytes = state_bytes + JT_WORDS * 8 + 2 * (64 + (uint64_t)max_found * sizeof(DpRecord));
     *out = h;
     return KNG_OK;
 }
@@ -794,7 +678,6 @@ void kng_destroy(kng_engine *h) {
     if (h->copy) (void)hipStreamSynchronize(h->copy);
     if (h->planes) (void)hipFree(h->planes);
     if (h->jtab) (void)hipFree(h->jtab);
-    if (h->jtab29) (void)hipFree(h->jtab29);
     for (int s = 0; s < 2; s++) {
         if (h->dp_count[s]) (void)hipFree(h->dp_count[s]);
         if (h->dp_items[s]) (void)hipFree(h->dp_items[s]);
@@ -829,11 +712,6 @@ int kng_set_option(kng_engine *h, const char *key, int64_t value) {
     } else if (k == "block") {
         if (value < 64 || value > 256 || (value % 64)) return fail(KNG_E_ARG, "block must be 64,128,192 or 256");
         h->block = (uint32_t)value;
-    } else if (k == "arith") {
-        if (value != 29 && value != 32) return fail(KNG_E_ARG, "arith must be 29 or 32");
-        if (h->have_herd) return fail(KNG_E_STATE, "arith must be chosen before kng_set_kangaroos");
-        h->arith = (int)value;
-        decide_dsplit(h);
     } else if (k == "steps") {
         if (value < 1 || value > 1 << 20) return fail(KNG_E_ARG, "steps out of range");
         h->nsteps = (uint32_t)value;
@@ -856,7 +734,6 @@ int kng_get_option(const kng_engine *h, const char *key, int64_t *value) {
     if (k == "group") *value = h->group;
     else if (k == "block") *value = h->block;
     else if (k == "steps") *value = h->nsteps;
-    else if (k == "arith") *value = h->arith;
     else if (k == "lanes") *value = h->lanes;
     else if (k == "share") *value = h->share;
     else if (k == "dsplit") *value = h->dsplit_on ? 1 : 0;
@@ -885,35 +762,8 @@ int kng_set_params(kng_engine *h, uint64_t dp_mask, const uint64_t *jd, const ui
         else if (h->jd_max != UINT64_MAX && jd[2 * j] > h->jd_max) h->jd_max = jd[2 * j];
     }
     decide_dsplit(h);
-    // policy 29: biased negations 2p - Jx, 2p - Jy as 29-bit limbs, limb-major; d as four dwords
-    uint32_t tab29[JT29_WORDS];
-    static const uint32_t P29x2[9] = {0x3FFFF85Eu, 0x3FFFFFEEu, 0x3FFFFFFEu, 0x3FFFFFFEu, 0x3FFFFFFEu,
-                                      0x3FFFFFFEu, 0x3FFFFFFEu, 0x3FFFFFFEu, 0x01FFFFFEu};
-    for (int j = 0; j < KNG_NB_JUMP; j++) {
-        uint32_t lx[9], ly[9];
-        uint64_t cx[4], cy[4];
-        host_unpack29(jx + 4 * j, lx);
-        host_canon256(lx, cx); // jump points are canonical already; this also rejects nothing
-        host_unpack29(cx, lx);
-        host_unpack29(jy + 4 * j, ly);
-        host_canon256(ly, cy);
-        host_unpack29(cy, ly);
-        for (int i = 0; i < 9; i++) {
-            tab29[JT29_NJX + 32 * i + j] = P29x2[i] - lx[i];
-            tab29[JT29_NJY + 32 * i + j] = P29x2[i] - ly[i];
-        }
-        tab29[JT29_JD + j] = (uint32_t)jd[2 * j];
-        tab29[JT29_JD + 32 + j] = (uint32_t)(jd[2 * j] >> 32);
-        tab29[JT29_JD + 64 + j] = (uint32_t)jd[2 * j + 1];
-        tab29[JT29_JD + 96 + j] = (uint32_t)(jd[2 * j + 1] >> 32);
-    }
-    // DP mask over x.limb3 (bits 192..255) spread over the 29-bit limbs 8 (232..255), 7 (203..231), 6 (192..202)
-    h->m8 = (uint32_t)(dp_mask >> 40);
-    h->m7 = (uint32_t)(dp_mask >> 11) & 0x1FFFFFFFu;
-    h->m6 = ((uint32_t)dp_mask & 0x7FFu) << 18;
     // stream-ordered after any in-flight launch
     HIP_TRY(hipMemcpyAsync(h->jtab, tab, sizeof tab, hipMemcpyHostToDevice, h->walk));
-    HIP_TRY(hipMemcpyAsync(h->jtab29, tab29, sizeof tab29, hipMemcpyHostToDevice, h->walk));
     HIP_TRY(hipStreamSynchronize(h->walk));
     h->dp_mask = dp_mask;
     h->have_params = true;
@@ -934,47 +784,20 @@ int kng_set_kangaroos_range(kng_engine *h, uint64_t first, uint64_t count, const
     if (xs < 4 || ys < 4 || ds < 2) return fail(KNG_E_ARG, "bad stride");
     HIP_TRY(hipSetDevice(h->dev));
     const size_t C = h->stage_kang;
-    // x, y, d address kangaroo `first` at index 0
-    x -= first * xs;
-    y -= first * ys;
-    d -= first * ds;
-    const uint64_t n = first + count;
-    for (uint64_t c0 = first; c0 < n; c0 += C) {
-        const size_t m = (size_t)((n - c0 < C) ? (n - c0) : C);
+    // the caller's arrays hold kangaroo first + r at index r
+    for (uint64_t r0 = 0; r0 < count; r0 += C) {
+        const size_t m = (size_t)((count - r0 < C) ? (count - r0) : C);
+        const uint64_t c0 = first + r0;
         v16 *st = h->h_stage;
         uint64_t *sd = reinterpret_cast<uint64_t *>(st + 4 * C); // d low words [C], high words [C]
-        if (h->arith == 29) {
-            uint4 *sq = reinterpret_cast<uint4 *>(st);
-            uint32_t *sc = reinterpret_cast<uint32_t *>(st + 5 * C); // xc[C] then yc[C]
-            for (size_t i = 0; i < m; i++) {
-                const uint64_t *px = x + (c0 + i) * xs, *py = y + (c0 + i) * ys, *pd = d + (c0 + i) * ds;
-                uint32_t l[9];
-                uint64_t cv[4];
-                host_unpack29(px, l);
-                host_canon256(l, cv); // x steers the walk: it must be canonical on the device
-                host_unpack29(cv, l);
-                sq[0 * C + i] = make_uint4(l[0], l[1], l[2], l[3]);
-                sq[1 * C + i] = make_uint4(l[4], l[5], l[6], l[7]);
-                sc[i] = l[8];
-                host_unpack29(py, l);
-                sq[2 * C + i] = make_uint4(l[0], l[1], l[2], l[3]);
-                sq[3 * C + i] = make_uint4(l[4], l[5], l[6], l[7]);
-                sc[C + i] = l[8];
-                sd[i] = pd[0];
-                sd[C + i] = pd[1];
-            }
-            for (int k = 0; k < 2; k++)
-                HIP_TRY(hipMemcpyAsync(plane_c(h, k) + c0, sc + (size_t)k * C, m * sizeof(uint32_t), hipMemcpyHostToDevice, h->walk));
-        } else {
-            for (size_t i = 0; i < m; i++) {
-                const uint64_t *px = x + (c0 + i) * xs, *py = y + (c0 + i) * ys, *pd = d + (c0 + i) * ds;
-                st[0 * C + i] = make_ulonglong2(px[0], px[1]);
-                st[1 * C + i] = make_ulonglong2(px[2], px[3]);
-                st[2 * C + i] = make_ulonglong2(py[0], py[1]);
-                st[3 * C + i] = make_ulonglong2(py[2], py[3]);
-                sd[i] = pd[0];
-                sd[C + i] = pd[1];
-            }
+        for (size_t i = 0; i < m; i++) {
+            const uint64_t *px = x + (r0 + i) * xs, *py = y + (r0 + i) * ys, *pd = d + (r0 + i) * ds;
+            st[0 * C + i] = make_ulonglong2(px[0], px[1]);
+            st[1 * C + i] = make_ulonglong2(px[2], px[3]);
+            st[2 * C + i] = make_ulonglong2(py[0], py[1]);
+            st[3 * C + i] = make_ulonglong2(py[2], py[3]);
+            sd[i] = pd[0];
+            sd[C + i] = pd[1];
         }
         for (int k = 0; k < 4; k++)
             HIP_TRY(hipMemcpyAsync(plane(h, k) + c0, st + (size_t)k * C, m * sizeof(v16), hipMemcpyHostToDevice, h->walk));
@@ -983,7 +806,7 @@ int kng_set_kangaroos_range(kng_engine *h, uint64_t first, uint64_t count, const
         HIP_TRY(hipStreamSynchronize(h->walk)); // staging buffer is reused
     }
     // the herd counts as loaded once its last kangaroo has been written (ranges are normally uploaded in order)
-    if (n == h->n) h->have_herd = true;
+    if (first + count == h->n) h->have_herd = true;
     return KNG_OK;
 }
 
@@ -1001,12 +824,9 @@ int kng_get_kangaroos_range(kng_engine *h, uint64_t first, uint64_t count, uint6
     if (!h->have_herd) return fail(KNG_E_STATE, "no herd loaded");
     HIP_TRY(hipSetDevice(h->dev));
     const size_t C = h->stage_kang;
-    x -= first * xs;
-    y -= first * ys;
-    d -= first * ds;
-    const uint64_t n = first + count;
-    for (uint64_t c0 = first; c0 < n; c0 += C) {
-        const size_t m = (size_t)((n - c0 < C) ? (n - c0) : C);
+    for (uint64_t r0 = 0; r0 < count; r0 += C) {
+        const size_t m = (size_t)((count - r0 < C) ? (count - r0) : C);
+        const uint64_t c0 = first + r0;
         v16 *st = h->h_stage;
         uint64_t *sd = reinterpret_cast<uint64_t *>(st + 4 * C); // d low words [C], high words [C]
         // stream-ordered behind an in-flight launch: returns the state that launch leaves
@@ -1014,30 +834,12 @@ int kng_get_kangaroos_range(kng_engine *h, uint64_t first, uint64_t count, uint6
             HIP_TRY(hipMemcpyAsync(st + (size_t)k * C, plane(h, k) + c0, m * sizeof(v16), hipMemcpyDeviceToHost, h->walk));
         for (int k = 0; k < 2; k++)
             HIP_TRY(hipMemcpyAsync(sd + (size_t)k * C, dplane(h, k) + c0, m * sizeof(uint64_t), hipMemcpyDeviceToHost, h->walk));
-        uint32_t *sc = reinterpret_cast<uint32_t *>(st + 5 * C);
-        if (h->arith == 29)
-            for (int k = 0; k < 2; k++)
-                HIP_TRY(hipMemcpyAsync(sc + (size_t)k * C, plane_c(h, k) + c0, m * sizeof(uint32_t), hipMemcpyDeviceToHost, h->walk));
         HIP_TRY(hipStreamSynchronize(h->walk));
-        if (h->arith == 29) {
-            const uint4 *sq = reinterpret_cast<const uint4 *>(st);
-            for (size_t i = 0; i < m; i++) {
-                uint64_t *px = x + (c0 + i) * xs, *py = y + (c0 + i) * ys, *pd = d + (c0 + i) * ds;
-                const uint4 a = sq[0 * C + i], b = sq[1 * C + i], e = sq[2 * C + i], f = sq[3 * C + i];
-                const uint32_t lx[9] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, sc[i]};
-                const uint32_t ly[9] = {e.x, e.y, e.z, e.w, f.x, f.y, f.z, f.w, sc[C + i]};
-                host_canon256(lx, px); // x is canonical on the device already; y is only almost reduced
-                host_canon256(ly, py);
-                pd[0] = sd[i];
-                pd[1] = sd[C + i];
-            }
-        } else {
-            for (size_t i = 0; i < m; i++) {
-                uint64_t *px = x + (c0 + i) * xs, *py = y + (c0 + i) * ys, *pd = d + (c0 + i) * ds;
-                px[0] = st[0 * C + i].x; px[1] = st[0 * C + i].y; px[2] = st[1 * C + i].x; px[3] = st[1 * C + i].y;
-                py[0] = st[2 * C + i].x; py[1] = st[2 * C + i].y; py[2] = st[3 * C + i].x; py[3] = st[3 * C + i].y;
-                pd[0] = sd[i]; pd[1] = sd[C + i];
-            }
+        for (size_t i = 0; i < m; i++) {
+            uint64_t *px = x + (r0 + i) * xs, *py = y + (r0 + i) * ys, *pd = d + (r0 + i) * ds;
+            px[0] = st[0 * C + i].x; px[1] = st[0 * C + i].y; px[2] = st[1 * C + i].x; px[3] = st[1 * C + i].y;
+            py[0] = st[2 * C + i].x; py[1] = st[2 * C + i].y; py[2] = st[3 * C + i].x; py[3] = st[3 * C + i].y;
+            pd[0] = sd[i]; pd[1] = sd[C + i];
         }
     }
     return KNG_OK;
@@ -1048,7 +850,6 @@ int kng_build_herd(kng_engine *h, int range_power, uint64_t seed, const uint64_t
     if (!h || !table || !base_tame || !base_wild || !final_add) return fail(KNG_E_ARG, "null argument");
     if (range_power < 1 || range_power > 128) return fail(KNG_E_ARG, "range_power must be 1..128");
     if (windows != (uint32_t)(range_power + 7) / 8) return fail(KNG_E_ARG, "windows must be ceil(range_power/8)");
-    if (h->arith != 32) return fail(KNG_E_STATE, "device herd creation needs walk policy arith=32");
     if (h->outstanding) return fail(KNG_E_STATE, "a launch is outstanding");
     HIP_TRY(hipSetDevice(h->dev));
     DevBuf dtab;
@@ -1079,20 +880,9 @@ int kng_set_kangaroo(kng_engine *h, uint64_t kidx, const uint64_t x[4], const ui
     if (!h || !x || !y || !d) return fail(KNG_E_ARG, "null argument");
     if (kidx >= h->n) return fail(KNG_E_ARG, "kIdx %llu out of range", (unsigned long long)kidx);
     HIP_TRY(hipSetDevice(h->dev));
-    if (h->arith == 29) {
-        fe29 fx, fy;
-        uint64_t cv[4];
-        host_unpack29(x, fx.l);
-        host_canon256(fx.l, cv);
-        host_unpack29(cv, fx.l);
-        host_unpack29(y, fy.l);
-        hipLaunchKernelGGL(kng_patch29_kernel, dim3(1), dim3(1), 0, h->walk, planes29(h, 0), planes29(h, 1), plane(h, 4), h->n, kidx,
-                           fx, fy, make_ulonglong2(d[0], d[1]));
-    } else {
-        fe fx{{x[0], x[1], x[2], x[3]}}, fy{{y[0], y[1], y[2], y[3]}};
-        hipLaunchKernelGGL(kng_patch_kernel, dim3(1), dim3(1), 0, h->walk, plane(h, 0), plane(h, 1), plane(h, 2), plane(h, 3),
-                           plane(h, 4), h->n, kidx, fx, fy, make_ulonglong2(d[0], d[1]));
-    }
+    const fe fx{{x[0], x[1], x[2], x[3]}}, fy{{y[0], y[1], y[2], y[3]}};
+    hipLaunchKernelGGL(kng_patch_kernel, dim3(1), dim3(1), 0, h->walk, plane(h, 0), plane(h, 1), plane(h, 2), plane(h, 3), plane(h, 4),
+                       h->n, kidx, fx, fy, make_ulonglong2(d[0], d[1]));
     HIP_TRY(hipGetLastError());
     return KNG_OK;
 }
@@ -1119,36 +909,16 @@ int kng_launch(kng_engine *h) {
     HIP_TRY(hipMemsetAsync(h->dp_count[s], 0, 4, h->walk)); // GPUEngine.cu:543
     HIP_TRY(hipEventRecord(h->ev_start[s], h->walk));
     const uint32_t blocks = (h->lanes + h->block - 1) / h->block;
-    if (h->arith == 29) {
-        Walk29Args b;
-        b.x = planes29(h, 0);
-        b.y = planes29(h, 1);
-        b.s = planes29(h, 2);
-        b.d = plane(h, 4);
-        b.jtab = h->jtab29;
-        b.m8 = h->m8;
-        b.m7 = h->m7;
-        b.m6 = h->m6;
-        b.dp_count = h->dp_count[s];
-        b.dp_items = h->dp_items[s];
-        b.max_found = h->max_found;
-        b.lanes = h->lanes;
-        b.group = h->group;
-        b.n_kang = h->n;
-        b.nsteps = h->nsteps;
-        hipLaunchKernelGGL(kng_walk29_kernel, dim3(blocks), dim3(h->block), 0, h->walk, b);
+    const bool ds = h->dsplit_on;
+    if (h->share == 2) {
+        if (ds) hipLaunchKernelGGL((kng_walk_share_kernel<2, true>), dim3((h->lanes + 511) / 512), dim3(512), 0, h->walk, a);
+        else hipLaunchKernelGGL((kng_walk_share_kernel<2, false>), dim3((h->lanes + 511) / 512), dim3(512), 0, h->walk, a);
+    } else if (h->share == 3) {
+        if (ds) hipLaunchKernelGGL((kng_walk_share_kernel<3, true>), dim3((h->lanes + 767) / 768), dim3(768), 0, h->walk, a);
+        else hipLaunchKernelGGL((kng_walk_share_kernel<3, false>), dim3((h->lanes + 767) / 768), dim3(768), 0, h->walk, a);
     } else {
-        const bool ds = h->dsplit_on;
-        if (h->share == 2) {
-            if (ds) hipLaunchKernelGGL((kng_walk_share_kernel<2, true>), dim3((h->lanes + 511) / 512), dim3(512), 0, h->walk, a);
-            else hipLaunchKernelGGL((kng_walk_share_kernel<2, false>), dim3((h->lanes + 511) / 512), dim3(512), 0, h->walk, a);
-        } else if (h->share == 3) {
-            if (ds) hipLaunchKernelGGL((kng_walk_share_kernel<3, true>), dim3((h->lanes + 767) / 768), dim3(768), 0, h->walk, a);
-            else hipLaunchKernelGGL((kng_walk_share_kernel<3, false>), dim3((h->lanes + 767) / 768), dim3(768), 0, h->walk, a);
-        } else {
-            if (ds) hipLaunchKernelGGL(kng_walk_dsplit_kernel, dim3(blocks), dim3(h->block), 0, h->walk, a);
-            else hipLaunchKernelGGL(kng_walk_kernel, dim3(blocks), dim3(h->block), 0, h->walk, a);
-        }
+        if (ds) hipLaunchKernelGGL(kng_walk_dsplit_kernel, dim3(blocks), dim3(h->block), 0, h->walk, a);
+        else hipLaunchKernelGGL(kng_walk_kernel, dim3(blocks), dim3(h->block), 0, h->walk, a);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev_stop[s], h->walk));
@@ -1237,7 +1007,7 @@ int kng_last_kernel_ms(const kng_engine *h, float *ms) {
 
 int kng_test_fieldop(int dev, int op, const uint64_t *a, const uint64_t *b, uint64_t *r, uint64_t n) {
     if (!a || !b || !r) return fail(KNG_E_ARG, "null argument");
-    if (op < KNG_OP_MODMUL || op > KNG_OP_JUMP29_DX) return fail(KNG_E_ARG, "unknown op %d", op);
+    if (op < KNG_OP_MODMUL || op > KNG_OP_MODINV) return fail(KNG_E_ARG, "unknown op %d", op);
     if (n == 0) return KNG_OK;
     if (dev < 0 || dev >= kng_device_count()) return fail(KNG_E_NODEVICE, "invalid device %d (no CPU fallback)", dev);
     HIP_TRY(hipSetDevice(dev));

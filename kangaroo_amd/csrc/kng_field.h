@@ -81,109 +81,6 @@ KNG_DEV fe fe_sub(const fe &a, const fe &b) {
                (uint64_t)r[4] | ((uint64_t)r[5] << 32), (uint64_t)r[6] | ((uint64_t)r[7] << 32)}};
 }
 
-// 512 -> 320 -> 256 fold (GPUMath.h:840-856 / IntMod.cpp:926-942)
-KNG_DEV fe fe_fold(const uint64_t w[8]) {
-    // t[0..4] = w[4..7] * K1C
-    uint64_t t[5];
-    u128 c = (u128)w[4] * K1C;
-    t[0] = (uint64_t)c;
-    c = (c >> 64) + (u128)w[5] * K1C;
-    t[1] = (uint64_t)c;
-    c = (c >> 64) + (u128)w[6] * K1C;
-    t[2] = (uint64_t)c;
-    c = (c >> 64) + (u128)w[7] * K1C;
-    t[3] = (uint64_t)c;
-    t[4] = (uint64_t)(c >> 64);
-    fe r;
-    unsigned long long cy = 0;
-    r.v[0] = __builtin_addcll(w[0], t[0], 0, &cy);
-    r.v[1] = __builtin_addcll(w[1], t[1], cy, &cy);
-    r.v[2] = __builtin_addcll(w[2], t[2], cy, &cy);
-    r.v[3] = __builtin_addcll(w[3], t[3], cy, &cy);
-    // second fold: (t[4] + carry) * K1C, t[4]+carry <= K1C so no overflow
-    const u128 f = (u128)(t[4] + cy) * K1C;
-    r.v[0] = __builtin_addcll(r.v[0], (uint64_t)f, 0, &cy);
-    r.v[1] = __builtin_addcll(r.v[1], (uint64_t)(f >> 64), cy, &cy);
-    r.v[2] = __builtin_addcll(r.v[2], 0, cy, &cy);
-    r.v[3] = __builtin_addcll(r.v[3], 0, cy, &cy);
-    // final carry dropped on purpose: identical to the reference (IntMod.cpp:944)
-    return r;
-}
-
-KNG_DEV fe fe_mul_c64(const fe &a, const fe &b) {
-    uint64_t w[8];
-    // row 0
-    u128 c = (u128)a.v[0] * b.v[0];
-    w[0] = (uint64_t)c;
-    c = (c >> 64) + (u128)a.v[1] * b.v[0];
-    w[1] = (uint64_t)c;
-    c = (c >> 64) + (u128)a.v[2] * b.v[0];
-    w[2] = (uint64_t)c;
-    c = (c >> 64) + (u128)a.v[3] * b.v[0];
-    w[3] = (uint64_t)c;
-    w[4] = (uint64_t)(c >> 64);
-#pragma unroll
-    for (int i = 1; i < 4; i++) {
-        c = (u128)a.v[0] * b.v[i] + w[i];
-        w[i] = (uint64_t)c;
-        c = (c >> 64) + (u128)a.v[1] * b.v[i] + w[i + 1];
-        w[i + 1] = (uint64_t)c;
-        c = (c >> 64) + (u128)a.v[2] * b.v[i] + w[i + 2];
-        w[i + 2] = (uint64_t)c;
-        c = (c >> 64) + (u128)a.v[3] * b.v[i] + w[i + 3];
-        w[i + 3] = (uint64_t)c;
-        w[i + 4] = (uint64_t)(c >> 64);
-    }
-    return fe_fold(w);
-}
-
-KNG_DEV fe fe_sqr_c64(const fe &a) {
-    // 10 distinct products: 4 squares + 6 cross terms added twice (GPUMath.h:913-1019 idea;
-    // the result is the same 512-bit integer as a*a, so the fold is bit-identical)
-    uint64_t w[8];
-    // cross terms: sum_{i<j} a_i a_j 2^(64(i+j))
-    u128 c = (u128)a.v[0] * a.v[1];
-    uint64_t x1 = (uint64_t)c;
-    c = (c >> 64) + (u128)a.v[0] * a.v[2];
-    uint64_t x2 = (uint64_t)c;
-    c = (c >> 64) + (u128)a.v[0] * a.v[3];
-    uint64_t x3 = (uint64_t)c;
-    uint64_t x4 = (uint64_t)(c >> 64);
-    c = (u128)a.v[1] * a.v[2] + x3;
-    x3 = (uint64_t)c;
-    c = (c >> 64) + (u128)a.v[1] * a.v[3] + x4;
-    x4 = (uint64_t)c;
-    uint64_t x5 = (uint64_t)(c >> 64);
-    c = (u128)a.v[2] * a.v[3] + x5;
-    x5 = (uint64_t)c;
-    uint64_t x6 = (uint64_t)(c >> 64);
-    // double
-    uint64_t x7 = x6 >> 63;
-    x6 = (x6 << 1) | (x5 >> 63);
-    x5 = (x5 << 1) | (x4 >> 63);
-    x4 = (x4 << 1) | (x3 >> 63);
-    x3 = (x3 << 1) | (x2 >> 63);
-    x2 = (x2 << 1) | (x1 >> 63);
-    x1 = x1 << 1;
-    // add squares
-    c = (u128)a.v[0] * a.v[0];
-    w[0] = (uint64_t)c;
-    c = (c >> 64) + x1;
-    w[1] = (uint64_t)c;
-    c = (c >> 64) + (u128)a.v[1] * a.v[1] + x2;
-    w[2] = (uint64_t)c;
-    c = (c >> 64) + x3;
-    w[3] = (uint64_t)c;
-    c = (c >> 64) + (u128)a.v[2] * a.v[2] + x4;
-    w[4] = (uint64_t)c;
-    c = (c >> 64) + x5;
-    w[5] = (uint64_t)c;
-    c = (c >> 64) + (u128)a.v[3] * a.v[3] + x6;
-    w[6] = (uint64_t)c;
-    w[7] = (uint64_t)(c >> 64) + x7;
-    return fe_fold(w);
-}
-
 } // namespace kng
 
 #include "kng_mul32.h"
@@ -254,9 +151,6 @@ KNG_DEV fe fe_mul_c32(const fe &a, const fe &b) {
     return fe_fold32(w);
 }
 
-#ifndef KNG_MUL_IMPL
-#define KNG_MUL_IMPL 32
-#endif
 // a^2 with the 36-MAD squaring schedule (sqr_wide32) -- same 512-bit integer, same fold
 KNG_DEV fe fe_sqr_c32(const fe &a) {
     uint32_t x[8], w[16];
@@ -265,13 +159,8 @@ KNG_DEV fe fe_sqr_c32(const fe &a) {
     return fe_fold32(w);
 }
 
-#if KNG_MUL_IMPL == 32
 KNG_DEV fe fe_mul(const fe &a, const fe &b) { return fe_mul_c32(a, b); }
 KNG_DEV fe fe_sqr(const fe &a) { return fe_sqr_c32(a); }
-#else
-KNG_DEV fe fe_mul(const fe &a, const fe &b) { return fe_mul_c64(a, b); }
-KNG_DEV fe fe_sqr(const fe &a) { return fe_sqr_c64(a); }
-#endif
 
 // full reduction of a value in [0,2^256) into [0,p)
 KNG_DEV fe fe_canon(const fe &a) {

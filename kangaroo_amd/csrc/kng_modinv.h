@@ -11,8 +11,8 @@
 // (the inner step is ~17 and/xor/add/shift instructions with the matrix rows packed two per register, no
 // branches); the
 // 2x2 transition matrix of each 30-step block is applied to the 9-limb f,g / d,e with
-// v_mad_i64_i32.  Measured ~7x cheaper than the Fermat ladder a^(p-2) (kept below as
-// fe_inv_fermat for cross-checking).
+// v_mad_i64_i32.  Measured ~7x cheaper than the Fermat ladder a^(p-2)
+// (tools/fe_extras.h keeps one for cross-checking).
 #pragma once
 
 #include "kng_field.h"
@@ -227,35 +227,6 @@ KNG_DEV_NOINLINE fe fe_inv(const fe &a_in) {
     r.v[2] = ((uint64_t)(uint32_t)d[4] >> 8) | ((uint64_t)(uint32_t)d[5] << 22) | ((uint64_t)(uint32_t)d[6] << 52);
     r.v[3] = ((uint64_t)(uint32_t)d[6] >> 12) | ((uint64_t)(uint32_t)d[7] << 18) | ((uint64_t)(uint32_t)d[8] << 48);
     return r;
-}
-
-// ---- Fermat ladder a^(p-2): 255 squarings + 15 multiplications (cross-check only) ----
-KNG_DEV_NOINLINE fe fe_sqr_n(fe a, int n) {
-#pragma unroll 1
-    for (int i = 0; i < n; i++) a = fe_sqr(a);
-    return a;
-}
-KNG_DEV_NOINLINE fe fe_mul_noinline(const fe &a, const fe &b) { return fe_mul(a, b); }
-
-// p-2 = 2^256 - 2^32 - 979: 223 ones, 0, 22 ones, 0000, 1, 0, 11, 0, 1
-KNG_DEV_NOINLINE fe fe_inv_fermat(const fe &a_in) {
-    const fe a = fe_canon(a_in);
-    fe x2 = fe_mul_noinline(fe_sqr_n(a, 1), a);
-    fe x3 = fe_mul_noinline(fe_sqr_n(x2, 1), a);
-    fe x6 = fe_mul_noinline(fe_sqr_n(x3, 3), x3);
-    fe x9 = fe_mul_noinline(fe_sqr_n(x6, 3), x3);
-    fe x11 = fe_mul_noinline(fe_sqr_n(x9, 2), x2);
-    fe x22 = fe_mul_noinline(fe_sqr_n(x11, 11), x11);
-    fe x44 = fe_mul_noinline(fe_sqr_n(x22, 22), x22);
-    fe x88 = fe_mul_noinline(fe_sqr_n(x44, 44), x44);
-    fe x176 = fe_mul_noinline(fe_sqr_n(x88, 88), x88);
-    fe x220 = fe_mul_noinline(fe_sqr_n(x176, 44), x44);
-    fe x223 = fe_mul_noinline(fe_sqr_n(x220, 3), x3);
-    fe t = fe_mul_noinline(fe_sqr_n(x223, 23), x22);
-    t = fe_mul_noinline(fe_sqr_n(t, 5), a);
-    t = fe_mul_noinline(fe_sqr_n(t, 3), x2);
-    t = fe_mul_noinline(fe_sqr_n(t, 2), a);
-    return fe_canon(t);
 }
 
 } // namespace kng

@@ -107,7 +107,7 @@ def default_grid(dev: int = 0, x: int = 0, y: int = 0) -> tuple:
     return cx.value, cy.value
 
 
-OPS = {"modmul": 0, "modsqr": 1, "modsub": 2, "modinv": 3, "mul29": 4, "sub29": 5, "rx29": 6, "ry29": 7, "inv29": 8, "jump29": 9, "jump29_inv": 10, "jump29_s": 11, "jump29_rx": 12, "jump29_ry": 13, "jump29_dx": 14}
+OPS = {"modmul": 0, "modsqr": 1, "modsub": 2, "modinv": 3}
 
 
 def test_fieldop(op: str, a: np.ndarray, b: np.ndarray | None = None, dev: int = 0) -> np.ndarray:

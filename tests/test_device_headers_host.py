@@ -1,4 +1,4 @@
-"""The DEVICE field arithmetic (kangaroo_amd/csrc/kng_field.h, kng_modinv.h, kng_field29.h), compiled for
+"""The DEVICE field arithmetic (kangaroo_amd/csrc/kng_field.h, kng_modinv.h), compiled for
 the HOST with the ROCm clang++ and checked against the reference's golden vectors.
 
 No GPU needed: the headers are written so that everything except the inline-asm fast paths also compiles
@@ -62,15 +62,3 @@ def test_modinv_safegcd_and_fermat(golden, host_field):
     vals = [rnd.getrandbits(rnd.choice((8, 31, 64, 129, 200, 255, 256))) % P or 1 for _ in range(3000)]
     vals += [1, 2, P - 1, P - 2, (P + 1) // 2, 1 << 255, (1 << 256) - 1 - P]
     assert host_field([f"inv {v:064x} {v:064x}" for v in vals]) == [pow(v, P - 2, P) for v in vals]
-
-
-def test_radix29_ops_match_canonical_arithmetic(golden, host_field):
-    """Policy "29" works on lazy limbs; only canonical values are contractual."""
-    pairs = [(int(a, 16) % P, int(b, 16) % P) for a, b, _ in golden["modmul"][:400]]
-    h = lambda v: f"{v:064x}"  # noqa: E731
-    assert host_field([f"mul29 {h(a)} {h(b)}" for a, b in pairs]) == [a * b % P for a, b in pairs]
-    assert host_field([f"mul29lazy {h(a)} {h(b)}" for a, b in pairs]) == [(a - b) * b % P for a, b in pairs]
-    assert host_field([f"sub29 {h(a)} {h(b)}" for a, b in pairs]) == [(a - b) % P for a, b in pairs]
-    assert host_field([f"rx29 {h(a)} {h(b)}" for a, b in pairs]) == [(a * a - b - a) % P for a, b in pairs]
-    assert host_field([f"ry29 {h(a)} {h(b)}" for a, b in pairs]) == [((a - b) * a - b) % P for a, b in pairs]
-    assert host_field([f"canon29 {h(a)} {h(a)}" for a, _ in pairs]) == [a for a, _ in pairs]

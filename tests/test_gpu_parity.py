@@ -71,60 +71,6 @@ def test_primitives_random_vs_oracle(kng, orc, op):
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("op", ["mul29", "sub29", "rx29", "ry29", "inv29"])
-def test_radix29_primitives_vs_bigint(kng, op):
-    """The carry-free 9x29-bit arithmetic of walk policy 29: canonical results against Python integers,
-    on random operands, operands around p / 2^256 (non-canonical inputs) and tiny operands."""
-    from helpers import P
-
-    rng = np.random.default_rng(99)
-    n = 20000 if op != "inv29" else 4096
-    a = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
-    b = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
-    a[::97, 1:] = np.uint64(0xFFFFFFFFFFFFFFFF)   # >= p or just below
-    b[::89, 1:] = np.uint64(0xFFFFFFFFFFFFFFFF)
-    a[::101, 1:] = 0
-    b[::103, 1:] = 0
-    edge = [0, 1, 2, P - 1, P, P + 1, (1 << 256) - 1, (1 << 256) - 0x1000003D1 + 5, 1 << 255, (1 << 232) - 1]
-    for i, v in enumerate(edge):
-        a[i] = ints_to_array([v])[0]
-        b[(i * 7) % len(edge)] = ints_to_array([v])[0]
-    got = array_to_ints(kng.test_fieldop(op, a, b))
-    ai, bi = array_to_ints(a), array_to_ints(b)
-    f = {"mul29": lambda x, y: x * y % P, "sub29": lambda x, y: (x - y) % P, "rx29": lambda x, y: (x * x - y - x) % P,
-         "ry29": lambda x, y: ((x - y) * x - y) % P, "inv29": lambda x, y: pow(x % P, -1, P) if x % P else 0}[op]
-    want = [f(x, y) for x, y in zip(ai, bi)]
-    assert got == want
-
-
-def test_radix29_full_jump_sequence(kng):
-    """One complete jump in the exact operation order of the policy-29 kernel, with every
-    intermediate checked (this composition exposed a hipcc miscompile of fe29_canon that the
-    single-operation tests above do not see)."""
-    from helpers import P
-
-    rng = np.random.default_rng(3)
-    n = 4096
-    a = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
-    b = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
-    a[:, 3] >>= np.uint64(1)
-    b[:, 3] >>= np.uint64(1)
-    A, B = array_to_ints(a), array_to_ints(b)
-    exp = {k: [] for k in ("jump29_dx", "jump29_inv", "jump29_s", "jump29_rx", "jump29_ry", "jump29")}
-    for x, jx in zip(A, B):
-        y = (jx - x) % P
-        jy = ((jx ^ 1) & ((1 << 255) - 1)) % P
-        dx = (x - jx) % P
-        inv = pow(dx, -1, P)
-        s = (y - jy) * inv % P
-        rx = (s * s - jx - x) % P
-        ry = (s * (x - rx) - y) % P
-        for k_, v in zip(exp, (dx, inv, s, rx, ry, (rx - ry) % P)):
-            exp[k_].append(v)
-    for op, want in exp.items():
-        assert array_to_ints(kng.test_fieldop(op, a, b)) == want, op
-
-
 def test_fieldop_empty(kng):
     e = np.zeros((0, 4), dtype=np.uint64)
     assert kng.test_fieldop("modmul", e, e).shape == (0, 4)
@@ -156,12 +102,11 @@ def _run_check_protocol(kng, w, jd, jx, jy, grid, launches, **opts):
 @pytest.mark.parametrize("name,grid,launches", [("walk_check64", (2, 1), 1), ("walk_80", (1, 1), 1),
                                                 ("walk_125", (1, 1), 2)])
 @pytest.mark.parametrize("group", [1, 4, 128])
-@pytest.mark.parametrize("arith", [29, 32])
-def test_walk_matches_reference_vectors(kng, orc, golden, name, grid, launches, group, arith):
+def test_walk_matches_reference_vectors(kng, orc, golden, name, grid, launches, group):
     w = walk_fixture(golden[name])
     assert w["nsteps"] == 64 * launches
     jd, jx, jy, _ = orc.jump_table(w["range_power"])
-    end, dps = _run_check_protocol(kng, w, jd, jx, jy, grid, launches, group=group, arith=arith)
+    end, dps = _run_check_protocol(kng, w, jd, jx, jy, grid, launches, group=group)
     assert end == w["end"]
     assert dp_multiset(dps) == dp_multiset(w["dps"])
 
@@ -192,15 +137,14 @@ def _seeded_herd(orc, n, range_power, seed):
     ((2, 4), 128, 64, 2, 0),     # dp=0: every jump is a DP -> 64*n points, exercises max_found clamp
     ((8, 4), 64, 64, 1, 7),
 ])
-@pytest.mark.parametrize("arith", [29, 32])
-def test_walk_vs_oracle(kng, orc, grid, group, block, launches, dp, arith):
+def test_walk_vs_oracle(kng, orc, grid, group, block, launches, dp):
     n = grid[0] * grid[1] * 128
     rp = 72
     x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=grid[0] * 100 + group)
     jd, jx, jy, _ = orc.jump_table(rp)
     mask = orc.dp_mask(dp)
     max_found = 1 << 16
-    eng = kng.GPUEngine(grid[0], grid[1], 0, max_found, group=group, block=block, arith=arith)
+    eng = kng.GPUEngine(grid[0], grid[1], 0, max_found, group=group, block=block)
     eng.SetParams(mask, jd, jx, jy)
     eng.SetWildOffset(wild_offset)
     eng.SetKangaroos(x, y, ints_to_array(true_d))
@@ -226,8 +170,7 @@ def test_walk_vs_oracle(kng, orc, grid, group, block, launches, dp, arith):
     eng.close()
 
 
-@pytest.mark.parametrize("arith", [29, 32])
-def test_set_get_roundtrip_and_single_overwrite(kng, orc, arith):
+def test_set_get_roundtrip_and_single_overwrite(kng, orc):
     """SetKangaroos/GetKangaroos are exact inverses incl. the wild offset (GPUEngine.cu:381-480);
     SetKangaroo (GPUEngine.cu:483-538) lands after an in-flight launch."""
     grid = (2, 3)
@@ -235,7 +178,7 @@ def test_set_get_roundtrip_and_single_overwrite(kng, orc, arith):
     rp = 125
     x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=7)
     jd, jx, jy, _ = orc.jump_table(rp)
-    eng = kng.GPUEngine(grid[0], grid[1], 0, 4096, group=16, arith=arith)
+    eng = kng.GPUEngine(grid[0], grid[1], 0, 4096, group=16)
     eng.SetParams(orc.dp_mask(10), jd, jx, jy)
     eng.SetWildOffset(wild_offset)
     eng.SetKangaroos(x, y, ints_to_array(true_d))
@@ -291,8 +234,7 @@ def test_default_grid_and_banner(kng):
 
 
 # ------------------------------------------------------------------ BASELINE.json full size
-@pytest.mark.parametrize("arith", [32, 29])
-def test_full_size_herd_properties(kng, orc, arith):
+def test_full_size_herd_properties(kng, orc):
     """The headline herd (reference default grid 2*CU x 128 -> 2^23 kangaroos, 80-bit range, auto DP)
     for three launches, checked through size-independent properties:
       * the group invariant of the walk: after any number of jumps every kangaroo still sits at
@@ -319,7 +261,7 @@ def test_full_size_herd_properties(kng, orc, arith):
     launches = 3
     rng = np.random.default_rng(5)
     sample = np.sort(rng.choice(n, size=1536, replace=False))
-    with kng.GPUEngine(gx, gy, 0, 65536 * 2, arith=arith) as eng:
+    with kng.GPUEngine(gx, gy, 0, 65536 * 2) as eng:
         eng.SetParams(mask, jd, jx, jy)
         eng.SetWildOffset(woff)
         eng.SetKangaroos(x, y, dev_d)
@@ -546,9 +488,8 @@ def test_standalone_cpp_gpuengine(tmp_path):
     assert out.returncode == 0 and "CPP GPUEngine ok" in out.stdout, out.stdout[-1500:] + out.stderr[-500:]
 
 
-@pytest.mark.parametrize("arith", [32, 29])
 @pytest.mark.parametrize("grid,lanes", [((3, 5), 448), ((2, 3), 320), ((4, 4), 1984)])
-def test_ragged_groups_vs_oracle(kng, orc, grid, lanes, arith):
+def test_ragged_groups_vs_oracle(kng, orc, grid, lanes):
     """Free lane count ("lanes" option): the herd does not divide evenly, so waves walk ceil or floor
     of N/lanes kangaroos.  Same bit-exact comparison with the oracle, two launches."""
     n = grid[0] * grid[1] * 128
@@ -556,7 +497,7 @@ def test_ragged_groups_vs_oracle(kng, orc, grid, lanes, arith):
     x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=lanes)
     jd, jx, jy, _ = orc.jump_table(rp)
     mask = orc.dp_mask(5)
-    eng = kng.GPUEngine(grid[0], grid[1], 0, 1 << 16, lanes=lanes, arith=arith)
+    eng = kng.GPUEngine(grid[0], grid[1], 0, 1 << 16, lanes=lanes)
     assert eng.get_option("lanes") == lanes and n % lanes != 0
     eng.SetParams(mask, jd, jx, jy)
     eng.SetWildOffset(wild_offset)
@@ -630,8 +571,7 @@ def test_distance_low_word_streaming_is_chosen_by_the_jump_table(kng, orc):
     eng.close()
 
 
-@pytest.mark.parametrize("arith", [32, 29])
-def test_ranged_set_get_of_the_herd(kng, arith):
+def test_ranged_set_get_of_the_herd(kng):
     """kng_set_kangaroos_range / kng_get_kangaroos_range: the herd uploaded in uneven slices (crossing the 64 K
     staging chunk) equals a whole-herd upload, slices read back equal the whole-herd read, bad ranges are refused."""
     gx, gy = 40, 16  # 81 920 kangaroos: more than one staging chunk
@@ -642,7 +582,7 @@ def test_ranged_set_get_of_the_herd(kng, arith):
     x[:, 3] >>= np.uint64(2)
     y[:, 3] >>= np.uint64(2)
     d = rng.integers(0, 1 << 64, size=(n, 2), dtype=np.uint64)
-    eng = kng.GPUEngine(gx, gy, 0, 1 << 16, arith=arith)
+    eng = kng.GPUEngine(gx, gy, 0, 1 << 16)
     cuts = [0, 1, 4097, 65536, 65537, 70001, n]
     with pytest.raises(kng.EngineError):
         eng.GetKangaroosRange(0, 16)  # nothing loaded yet

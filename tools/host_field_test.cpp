@@ -6,7 +6,7 @@
 #include <string>
 #include "../kangaroo_amd/csrc/kng_field.h"
 #include "../kangaroo_amd/csrc/kng_modinv.h"
-#include "../kangaroo_amd/csrc/kng_field29.h"
+#include "fe_extras.h"
 using namespace kng;
 static fe parse(const char *s) {
     fe r{{0, 0, 0, 0}};
@@ -27,19 +27,6 @@ int main() {
         else if (!strcmp(op, "sub")) z = fe_sub(x, y);
         else if (!strcmp(op, "inv")) z = fe_inv(x);
         else if (!strcmp(op, "invf")) z = fe_inv_fermat(x);
-        else if (!strcmp(op, "mul29")) z = fe29_pack(fe29_canon(fe29_mul(fe29_unpack(x), fe29_unpack(y))));
-        else if (!strcmp(op, "mul29lazy")) { // a operand lazy: (x - y + 2p) * y
-            fe29 ux = fe29_unpack(x), uy = fe29_unpack(y);
-            z = fe29_pack(fe29_canon(fe29_mul(fe29_sub2p(ux, uy), uy)));
-        } else if (!strcmp(op, "sub29")) z = fe29_pack(fe29_canon(fe29_add(fe29_unpack(x), fe29_neg2p(fe29_unpack(y)))));
-        else if (!strcmp(op, "rx29")) { // x^2 - y - x, the shape of rx = s^2 - jx - px
-            fe29 ux = fe29_unpack(x), uy = fe29_unpack(y);
-            z = fe29_pack(fe29_canon(fe29_add(fe29_add(fe29_sqr(ux), fe29_neg2p(uy)), fe29_neg2p(ux))));
-        } else if (!strcmp(op, "ry29")) { // norm((x - y + 2p)*x - y + 2p) then canon: the shape of ry
-            fe29 ux = fe29_unpack(x), uy = fe29_unpack(y);
-            fe29 m = fe29_mul(fe29_sub2p(ux, uy), ux);
-            z = fe29_pack(fe29_canon(fe29_norm(fe29_sub2p(m, uy))));
-        } else if (!strcmp(op, "canon29")) z = fe29_pack(fe29_canon(fe29_unpack(x)));
         else return 2;
         printf("%016llx%016llx%016llx%016llx\n", (unsigned long long)z.v[3], (unsigned long long)z.v[2], (unsigned long long)z.v[1], (unsigned long long)z.v[0]);
     }

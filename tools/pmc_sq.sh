@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counter pass for the walk kernel (counters only, no tracing domains)
-# usage: bash tools/pmc_sq.sh <tag> <arith> [group]
-TAG=$1; AR=$2; G=${3:-64}
+# usage: bash tools/pmc_sq.sh <tag> [group]
+TAG=$1; G=${2:-64}
 OUT=$PWD/gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
 cat > /tmp/run_walk.py <<PY
@@ -14,7 +14,7 @@ x[:,3] >>= np.uint64(1); y[:,3] >>= np.uint64(1)
 d = rng.integers(0, 1<<62, size=(n,2), dtype=np.uint64)
 jd = rng.integers(0, 1<<40, size=(32,2), dtype=np.uint64); jd[:,1] = 0
 jx = rng.integers(0, 1<<63, size=(32,4), dtype=np.uint64); jy = rng.integers(0, 1<<63, size=(32,4), dtype=np.uint64)
-eng = k.GPUEngine(gx, gy, 0, 1<<17, group=$G, arith=$AR)
+eng = k.GPUEngine(gx, gy, 0, 1<<17, group=$G)
 eng.SetParams(0xFFFC000000000000, jd, jx, jy); eng.SetKangaroos(x, y, d)
 for _ in range(2):
     eng.callKernel(); eng.wait(); eng.drain(raw=True)

@@ -2,7 +2,7 @@
 # clocks and power while the walk kernel runs (evidence for "power-limited"): samples rocm-smi /
 # amd-smi once a second during a 12 s run of the sweep tool.
 OUT=$PWD/gpurun_out; mkdir -p $OUT
-python tools/sweep.py --launches 400 --groups 64 --blocks 256 --ariths ${1:-32} > $OUT/power_sweep.txt 2>&1 &
+python tools/sweep.py --launches 400 --groups 64 --blocks 256 > $OUT/power_sweep.txt 2>&1 &
 PID=$!
 sleep 4
 for i in 1 2 3 4 5; do

@@ -24,7 +24,6 @@ def main():
     ap.add_argument("--blocks", default="64,256")
     ap.add_argument("--launches", type=int, default=3)
     ap.add_argument("--dp", type=int, default=14)
-    ap.add_argument("--ariths", default="29,32")
     ap.add_argument("--shares", default="2", help="comma list of 1/2/3: waves per SIMD sharing one inversion")
     ap.add_argument("--dsplit", type=int, default=-1, help="-1 auto / 0 / 1: low-word streaming of the distances")
     ap.add_argument("--lanes", default="", help="explicit lane counts (ragged groups); overrides --groups")
@@ -42,10 +41,10 @@ def main():
     mask = (~((1 << (64 - a.dp)) - 1)) & ((1 << 64) - 1) if a.dp else 0
     print(f"herd {n} = 2^{np.log2(n):.2f} kangaroos, dp {a.dp}", flush=True)
     glist = [("lanes", int(v)) for v in a.lanes.split(",")] if a.lanes else [("group", int(v)) for v in a.groups.split(",")]
-    for ar, (gk, g), b, sh in ((ar, g, b, sh) for ar in (int(v) for v in a.ariths.split(",")) for g in glist
+    for (gk, g), b, sh in ((g, b, sh) for g in glist
                                for b in (int(v) for v in a.blocks.split(",")) for sh in (int(v) for v in a.shares.split(","))):
         if True:
-            eng = k.GPUEngine(gx, gy, 0, 1 << 17, block=b, arith=ar, share=sh, **({"dsplit": a.dsplit} if a.dsplit >= 0 else {}), **{gk: g})
+            eng = k.GPUEngine(gx, gy, 0, 1 << 17, block=b, share=sh, **({"dsplit": a.dsplit} if a.dsplit >= 0 else {}), **{gk: g})
             eng.SetParams(mask, jd, jx, jy)
             eng.SetKangaroos(x, y, d)
             eng.callKernel()
@@ -61,7 +60,7 @@ def main():
             wall = time.time() - t0
             kms = float(np.mean(ms))
             rate = n * 64 / (kms * 1e-3) / 1e6
-            print(f"arith {ar} share {sh} group {eng.get_option('group'):4d} block {b:4d} lanes {eng.get_option('lanes'):7d} waves/CU {eng.get_option('waves_per_cu'):3d}: "
+            print(f"share {sh} group {eng.get_option('group'):4d} block {b:4d} lanes {eng.get_option('lanes'):7d} waves/CU {eng.get_option('waves_per_cu'):3d}: "
                   f"kernel {kms:9.2f} ms  {rate:10.1f} MK/s  ({rate * 160 / 1e6:6.3f} TB/s @160B)  wall/launch {wall / a.launches * 1e3:8.2f} ms  DPs {nd}",
                   flush=True)
             eng.close()

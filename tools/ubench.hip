@@ -8,6 +8,7 @@
 #include <vector>
 #include "../kangaroo_amd/csrc/kng_field.h"
 #include "../kangaroo_amd/csrc/kng_modinv.h"
+#include "fe_extras.h"
 using namespace kng;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
