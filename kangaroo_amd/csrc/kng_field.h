@@ -89,9 +89,10 @@ namespace kng {
 
 #define KNG_ADDC32(x, y, ci, co) __builtin_addc((unsigned)(x), (unsigned)(y), (unsigned)(ci), (co))
 
-// Same fold on 32-bit words: S = lo + hi*K exactly, T = S >> 256 (<= K), r = (S mod 2^256) + T*K
-// mod 2^256 -- the integer the reference computes (last carry dropped).
-KNG_DEV fe fe_fold32(const uint32_t w[16]) {
+// 512 -> 256 fold on 32-bit words (GPUMath.h:840-856 / IntMod.cpp:926-942): S = lo + hi*K exactly,
+// T = S >> 256 (<= K), r = (S mod 2^256) + T*K mod 2^256 -- the integer the reference computes (last carry
+// dropped).  General form, every carry rippled: the rarely-taken twin of fe_fold32 below.
+KNG_DEV fe fe_fold32_full(const uint32_t w[16]) {
     unsigned zero = 0; // opaque zero: see fe_sub
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
     asm("" : "+v"(zero));
@@ -135,6 +136,68 @@ KNG_DEV fe fe_fold32(const uint32_t w[16]) {
                (uint64_t)r[4] | ((uint64_t)r[5] << 32), (uint64_t)r[6] | ((uint64_t)r[7] << 32)}};
 }
 
+
+// d = a*b + c (32x32+64 -> 64), carry-out of the 64-bit sum in `co` (an SGPR lane mask on the device: the
+// conditions below are therefore wave-uniform "some lane overflowed" tests that cost no VALU instruction)
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#define KNG_MAD64(d, co, a, b, c) asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(co) : "v"(a), "s"(b), "v"(c))
+#else
+#define KNG_MAD64(d, co, a, b, c)                                                                          \
+    do {                                                                                                   \
+        const uint64_t p_ = (uint64_t)(a) * (b), c_ = (c);                                                 \
+        d = p_ + c_;                                                                                       \
+        co = (uint64_t)(d < p_);                                                                           \
+    } while (0)
+#endif
+
+// The same fold, arranged so that the common case needs ONE carry chain instead of three.
+// hi*K = hi*977 + (hi << 32).  A v_mad_u64_u32 adds a 64-bit value for free, and the eight products hi_j*977
+// (< 2^42) at even j do not overlap each other, nor do those at odd j:
+//     E_j = hi_j*977 + (lo_j | lo_j+1 << 32)     j = 0,2,4,6   -> the number  lo + sum_even hi_j*977*2^(32j)
+//     O_j = hi_j*977 + (hi_j-1 | hi_j << 32)     j = 1,3,5,7   -> (hi << 32) + sum_odd hi_j*977*2^(32j)
+// so S = E + O with E at limbs 0..7 and O at limbs 1..8: one 8-link chain.  A MAD overflows 64 bits only when its
+// addend is within 2^42 of 2^64 (2^-22 per MAD); T = S >> 256 exceeds 32 bits only when hi_7 is within 978 of 2^32;
+// the second fold's carry leaves limb 2 only when that limb is all ones.  Any of these is reported to the caller
+// (`rare`: wave-uniform lane mask of MAD overflows, ORed in; `lane`: this lane's two chain carries), who then folds
+// again on the exact path (fe_fold32_checked); tests/test_gpu_parity.py::test_fold_rare_paths and the host-compiled
+// header test hit each condition.  14 carry instructions fewer per product; measured +0.4 % on the walk
+// (profiles/r02_ab_single_chain_fold.txt) -- the eight lane-mask ORs it adds cost nearly as much as the carries.
+KNG_DEV fe fe_fold32(const uint32_t w[16], uint64_t &rare, unsigned &lane) {
+    unsigned zero = 0; // opaque zero: see fe_sub
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(zero));
+#endif
+    const uint32_t k977 = 977u;
+    uint64_t e[4], o[4], ce[4], co[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint64_t lp = (uint64_t)w[2 * j] | ((uint64_t)w[2 * j + 1] << 32);
+        const uint64_t hp = (uint64_t)w[8 + 2 * j] | ((uint64_t)w[9 + 2 * j] << 32);
+        KNG_MAD64(e[j], ce[j], w[8 + 2 * j], k977, lp);
+        KNG_MAD64(o[j], co[j], w[9 + 2 * j], k977, hp);
+    }
+    uint32_t s[9];
+    unsigned c = 0;
+    s[0] = (uint32_t)e[0];
+    s[1] = KNG_ADDC32((uint32_t)(e[0] >> 32), (uint32_t)o[0], c, &c);
+#pragma unroll
+    for (int j = 1; j < 4; j++) {
+        s[2 * j] = KNG_ADDC32((uint32_t)e[j], (uint32_t)(o[j - 1] >> 32), c, &c);
+        s[2 * j + 1] = KNG_ADDC32((uint32_t)(e[j] >> 32), (uint32_t)o[j], c, &c);
+    }
+    s[8] = KNG_ADDC32((uint32_t)(o[3] >> 32), zero, c, &c);
+    const unsigned top = c; // bit 32 of T
+    // second fold, T = s[8] < 2^32:  T*K = s8*977 + (s8 << 32)
+    uint64_t r01, c1;
+    KNG_MAD64(r01, c1, s[8], k977, (uint64_t)s[0] | ((uint64_t)s[1] << 32));
+    const uint32_t r1 = KNG_ADDC32((uint32_t)(r01 >> 32), s[8], 0u, &c);
+    const uint32_t r2 = KNG_ADDC32(s[2], zero, c, &c);
+    rare |= ce[0] | ce[1] | ce[2] | ce[3] | co[0] | co[1] | co[2] | co[3] | c1;
+    lane = top | c;
+    return fe{{(uint64_t)(uint32_t)r01 | ((uint64_t)r1 << 32), (uint64_t)r2 | ((uint64_t)s[3] << 32),
+               (uint64_t)s[4] | ((uint64_t)s[5] << 32), (uint64_t)s[6] | ((uint64_t)s[7] << 32)}};
+}
+
 KNG_DEV void fe_to32(uint32_t r[8], const fe &a) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -143,12 +206,26 @@ KNG_DEV void fe_to32(uint32_t r[8], const fe &a) {
     }
 }
 
+// Same integer as GPUMath.h:810-858 on every input: the single-chain fold first; when one of its "this cannot be
+// right" conditions holds in some lane (about once in 2^13 wave-products on random operands) the wave folds again
+// with every carry rippled.
+KNG_DEV fe fe_fold32_checked(const uint32_t w[16]) {
+    uint64_t rare = 0;
+    unsigned lane;
+    fe r = fe_fold32(w, rare, lane);
+    if (__builtin_expect((rare != 0) | (lane != 0), 0)) {
+        KNG_RARE_PATH();
+        r = fe_fold32_full(w);
+    }
+    return r;
+}
+
 KNG_DEV fe fe_mul_c32(const fe &a, const fe &b) {
     uint32_t x[8], y[8], w[16];
     fe_to32(x, a);
     fe_to32(y, b);
     mul_wide32(w, x, y);
-    return fe_fold32(w);
+    return fe_fold32_checked(w);
 }
 
 // a^2 with the 36-MAD squaring schedule (sqr_wide32) -- same 512-bit integer, same fold
@@ -156,7 +233,7 @@ KNG_DEV fe fe_sqr_c32(const fe &a) {
     uint32_t x[8], w[16];
     fe_to32(x, a);
     sqr_wide32(w, x);
-    return fe_fold32(w);
+    return fe_fold32_checked(w);
 }
 
 KNG_DEV fe fe_mul(const fe &a, const fe &b) { return fe_mul_c32(a, b); }

@@ -44,3 +44,83 @@ def dp_multiset(dps):
 def random_field_elems(rng: np.random.Generator, n: int) -> np.ndarray:
     a = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
     return a
+
+
+# ---- operands that drive kng_field.h's fe_fold32 through each rarely-taken branch ----
+_M32, _M64 = (1 << 32) - 1, (1 << 64) - 1
+
+
+def fold_rare_flags(a: int, b: int) -> set:
+    """Which rare conditions of fe_fold32's single-chain form (kng_field.h) the product a*b raises: the Python
+    restatement of its dataflow, used only to prove that the test vectors reach every branch."""
+    w = [((a * b) >> (32 * i)) & _M32 for i in range(16)]
+    flags = set()
+    e, o = [], []
+    for j in range(4):
+        v = w[8 + 2 * j] * 977 + (w[2 * j] | (w[2 * j + 1] << 32))
+        if v >> 64:
+            flags.add(f"ce{j}")
+        e.append(v & _M64)
+        v = w[9 + 2 * j] * 977 + (w[8 + 2 * j] | (w[9 + 2 * j] << 32))
+        if v >> 64:
+            flags.add(f"co{j}")
+        o.append(v & _M64)
+    if flags:
+        return flags  # the chain below is only meaningful without dropped carries
+    s = sum(e[j] << (64 * j) for j in range(4)) + (sum(o[j] << (64 * j) for j in range(4)) << 32)
+    sl = [(s >> (32 * i)) & _M32 for i in range(9)]
+    if s >> 288:
+        flags.add("top")
+    r01 = sl[8] * 977 + (sl[0] | (sl[1] << 32))
+    if r01 >> 64:
+        flags.add("c1")
+    r1 = ((r01 >> 32) & _M32) + sl[8]
+    if (sl[2] + (r1 >> 32)) >> 32:
+        flags.add("c3")
+    return flags
+
+
+def fold_rare_vectors(rng: np.random.Generator):
+    """(a, b) pairs reaching every rare branch of the fold, found by a seeded structured search."""
+    full = (1 << 256) - 1
+    want = {f"ce{j}" for j in range(4)} | {f"co{j}" for j in range(4)} | {"top", "c1", "c3"}
+    found, out = set(), []
+
+    def rnd():
+        return int.from_bytes(rng.bytes(32), "little")
+
+    def consider(a, b):
+        f = fold_rare_flags(a, b)
+        if f - found:
+            found.update(f)
+            out.append((a, b))
+
+    # a * (2^256 - 1) = a*2^256 - a : hi = a - 1, lo = 2^256 - a  -> shape the limbs of a
+    for j in range(4):
+        for _ in range(64):
+            a = rnd()
+            a &= ~(_M64 << (64 * j))
+            a |= int(rng.integers(1, 1 << 9)) << (64 * j)  # limb pair (small, 0): lo pair close to 2^64
+            consider(a | 1, full)
+            a2 = rnd() | (_M32 << (32 * (2 * j + 1)))  # odd limb all ones: (hi << 32) pair overflows
+            consider(a2 | 1, full)
+    # the rest only depends on S = lo + hi*K; with b = 2^256 - 1: S = 2^256 - K + a*(K - 1), K - 1 = 16 * (2^28 + 61),
+    # so the low 96 bits of S can be chosen freely (up to that factor 16) through the low bits of a
+    K = 0x1000003D1
+    odd_inv = pow((K - 1) >> 4, -1, 1 << 92)
+
+    def a_for_low_bits_of_s(target96, top_limb):
+        assert (target96 + K) % 16 == 0
+        low = (((target96 + K) % (1 << 96)) >> 4) * odd_inv % (1 << 92)
+        mid = rnd() & (((1 << 224) - 1) ^ ((1 << 96) - 1))
+        return low | mid | (top_limb << 224)
+
+    # c1: the second fold's MAD s8*977 + (s0, s1) overflows: (s0, s1) = 2^64 - 17, T = s8 ~ 1000
+    consider(a_for_low_bits_of_s((rnd() & (_M32 << 64)) | ((1 << 64) - 17), 1000), full)
+    # c3: no MAD overflow, r1 + s8 carries, limb 2 all ones: s = (15, 2^32 - 2, 2^32 - 1)
+    consider(a_for_low_bits_of_s((_M32 << 64) | ((_M32 - 1) << 32) | 15, 1000), full)
+    # top: T needs 33 bits: hi_7 = 2^32 - 977 and hi_6 in [953552, 954529) (see the derivation in fe_fold32)
+    for h6 in (953552, 954000, 954528):
+        consider((((_M32 - 976) << 224) | (h6 << 192) | (rnd() & ((1 << 192) - 1))) + 1, full)
+    return out, found, want
+

@@ -62,3 +62,19 @@ def test_modinv_safegcd_and_fermat(golden, host_field):
     vals = [rnd.getrandbits(rnd.choice((8, 31, 64, 129, 200, 255, 256))) % P or 1 for _ in range(3000)]
     vals += [1, 2, P - 1, P - 2, (P + 1) // 2, 1 << 255, (1 << 256) - 1 - P]
     assert host_field([f"inv {v:064x} {v:064x}" for v in vals]) == [pow(v, P - 2, P) for v in vals]
+
+
+def test_fold_rare_branches_bit_exact(host_field, orc):
+    """fe_fold32's single-chain form leaves through fe_fold32_full when a MAD overflows, T needs 33 bits or the
+    second fold ripples: vectors built to raise each of the 11 conditions, against the oracle's ModMulK1."""
+    import numpy as np
+
+    from tests.helpers import array_to_ints, fold_rare_vectors, ints_to_array
+
+    vecs, found, want = fold_rare_vectors(np.random.default_rng(5))
+    assert found >= want, want - found
+    a, b = ints_to_array([v[0] for v in vecs]), ints_to_array([v[1] for v in vecs])
+    exp = np.zeros_like(a)
+    for i in range(len(vecs)):
+        orc.lib.orc_modmul(exp[i], a[i], b[i])
+    assert host_field([f"mul {x:064x} {y:064x}" for x, y in vecs]) == array_to_ints(exp)

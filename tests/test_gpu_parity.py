@@ -71,6 +71,27 @@ def test_primitives_random_vs_oracle(kng, orc, op):
     assert np.array_equal(got, want)
 
 
+def test_fold_rare_paths(kng, orc):
+    """The multiplier's rarely-taken branches (kng_field.h fe_fold32 -> fe_fold32_full): operands built to raise each
+    condition, scattered among ordinary operands so that waves take the wave-uniform exit with mixed lanes."""
+    from helpers import fold_rare_vectors
+
+    rng = np.random.default_rng(5)
+    vecs, found, want = fold_rare_vectors(rng)
+    assert found >= want, want - found
+    n = 64 * 40
+    a = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    b = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
+    for i, (x, y) in enumerate(vecs):
+        for pos in (i * 67 + 3, n - 1 - i * 131):  # one per wave, varying lane
+            a[pos], b[pos] = ints_to_array([x])[0], ints_to_array([y])[0]
+    got = kng.test_fieldop("modmul", a, b)
+    exp = np.zeros_like(a)
+    for i in range(n):
+        orc.lib.orc_modmul(exp[i], a[i], b[i])
+    assert np.array_equal(got, exp)
+
+
 def test_fieldop_empty(kng):
     e = np.zeros((0, 4), dtype=np.uint64)
     assert kng.test_fieldop("modmul", e, e).shape == (0, 4)

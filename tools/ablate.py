@@ -67,10 +67,11 @@ def v_no_comba_carry(files):
 def v_no_fold(files):
     """512 -> 256 reduction replaced by a xor of the halves (ceiling for a cheaper fold)"""
     t = files["kng_field.h"]
-    t = sub1(t, "KNG_DEV fe fe_fold32(const uint32_t w[16]) {", "KNG_DEV fe fe_fold32(const uint32_t w[16]) {\n"
+    t = sub1(t, "KNG_DEV fe fe_fold32(const uint32_t w[16], uint64_t &rare, unsigned &lane) {", "KNG_DEV fe fe_fold32(const uint32_t w[16], uint64_t &rare, unsigned &lane) {\n"
+             "    lane = 0;\n"
              "    return fe{{(uint64_t)(w[0] ^ w[8]) | ((uint64_t)(w[1] ^ w[9]) << 32), (uint64_t)(w[2] ^ w[10]) | ((uint64_t)(w[3] ^ w[11]) << 32),\n"
              "               (uint64_t)(w[4] ^ w[12]) | ((uint64_t)(w[5] ^ w[13]) << 32), (uint64_t)(w[6] ^ w[14]) | ((uint64_t)(w[7] ^ w[15]) << 32)}};\n"
-             "}\nKNG_DEV fe fe_fold32_unused(const uint32_t w[16]) {", 1)
+             "}\nKNG_DEV fe fe_fold32_unused(const uint32_t w[16], uint64_t &rare, unsigned &lane) {", 1)
     files["kng_field.h"] = t
     return files
 

@@ -1,6 +1,7 @@
 // mem_power_probe.hip -- package power against HBM traffic: a 16 B/lane streaming copy (optionally throttled by
 // dependent VALU work per vector) runs for a few seconds while tools/ablate_run.py samples rocm-smi.
 // Gives the energy per byte moved through L2/fabric/HBM that DESIGN.md's energy budget of the walk kernel uses.
+// usage: mem_power_probe <mode> <spin> <seconds> [MiB per buffer]: small buffers stay in the 256 MiB Infinity Cache
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/mem_power_probe tools/mem_power_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -25,7 +26,7 @@ int main(int argc, char **argv) {
     const int mode = argc > 1 ? atoi(argv[1]) : 0;
     const int spin = argc > 2 ? atoi(argv[2]) : 0;
     const double seconds = argc > 3 ? atof(argv[3]) : 5.0;
-    const size_t n = (size_t)1 << 27; // 2 GiB per buffer
+    const size_t n = (argc > 4 ? (size_t)atof(argv[4]) : (size_t)2048) * 65536; // vectors per buffer; argv[4] = MiB per buffer (default 2 GiB)
     v2u64 *a, *b;
     hipMalloc(&a, n * 16);
     hipMalloc(&b, n * 16);
@@ -56,6 +57,6 @@ int main(int argc, char **argv) {
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     const double bytes = (double)n * 16 * (mode == 0 ? 2 : 1) * reps;
-    printf("mode %d (%s) spin %d: %.3f TB/s over %.1f s\n", mode, mode == 0 ? "copy" : mode == 1 ? "read" : "write", spin, bytes / (ms * 1e-3) / 1e12, ms * 1e-3);
+    printf("mode %d (%s) spin %d, %zu MiB/buffer: %.3f TB/s over %.1f s\n", mode, mode == 0 ? "copy" : mode == 1 ? "read" : "write", spin, n / 65536, bytes / (ms * 1e-3) / 1e12, ms * 1e-3);
     return 0;
 }
