@@ -123,6 +123,17 @@ int kng_wait(kng_engine *h, int spin);
  * (GPUEngine.cu:641-648).  May be called while the next launch is already running: DP buffers
  * are double-buffered. */
 int kng_drain(kng_engine *h, kng_item *items, uint32_t cap, uint32_t *n_items, uint32_t *n_lost);
+/* the same without the per-item copy: *records points at the engine's pinned landing buffer (64-byte records, the
+ * layout the kernel writes: OutputDP of GPUMath.h:173-188 padded to four 16-byte stores) holding *n_items points.
+ * The view stays valid until the next kng_drain / kng_drain_view of this engine.  For hosts that ingest ~10^5
+ * points per launch (many GPUs share a small DP size, Kangaroo.cpp:980-993). */
+typedef struct kng_dp_record {
+    uint64_t x[4];
+    uint64_t d[2]; /* device distance: wild kangaroos (odd kidx) still carry +wildOffset */
+    uint64_t kidx;
+    uint64_t reserved;
+} kng_dp_record;
+int kng_drain_view(kng_engine *h, const kng_dp_record **records, uint32_t *n_items, uint32_t *n_lost);
 
 /* ---- measurement (new; the reference only has the host-side MK/s average, Thread.cpp:254-300) */
 /* HIP-event duration (ms) of the walk kernel of the most recently waited launch, measured on

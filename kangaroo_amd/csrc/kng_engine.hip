@@ -965,10 +965,10 @@ int kng_wait(kng_engine *h, int spin) {
     return KNG_OK;
 }
 
-int kng_drain(kng_engine *h, kng_item *items, uint32_t cap, uint32_t *n_items, uint32_t *n_lost) {
-    if (!h || !n_items) return fail(KNG_E_ARG, "null argument");
-    *n_items = 0;
-    if (n_lost) *n_lost = 0;
+// copy the points of the most recently waited launch into the pinned landing buffer; *found <= min(max_found, cap)
+static int land_points(kng_engine *h, uint32_t cap, uint32_t *found_out, uint32_t *lost_out) {
+    *found_out = 0;
+    *lost_out = 0;
     if (h->slot_ready < 0) return KNG_OK; // nothing waited yet (first Launch of the reference protocol)
     HIP_TRY(hipSetDevice(h->dev));
     const int s = h->slot_ready;
@@ -982,20 +982,47 @@ int kng_drain(kng_engine *h, kng_item *items, uint32_t cap, uint32_t *n_items, u
         lost += found - cap;
         found = cap;
     }
-    if (found && !items) return fail(KNG_E_ARG, "null items with %u points pending", found);
     if (found) {
         HIP_TRY(hipMemcpyAsync(h->h_items, h->dp_items[s], (size_t)found * sizeof(DpRecord), hipMemcpyDeviceToHost, h->copy));
         HIP_TRY(hipStreamSynchronize(h->copy));
-        for (uint32_t i = 0; i < found; i++) {
-            memcpy(items[i].x, h->h_items[i].x, 32);
-            items[i].d[0] = h->h_items[i].d[0];
-            items[i].d[1] = h->h_items[i].d[1];
-            items[i].kidx = h->h_items[i].kidx;
-        }
+    }
+    *found_out = found;
+    *lost_out = lost;
+    h->slot_ready = -1; // drained
+    return KNG_OK;
+}
+
+int kng_drain(kng_engine *h, kng_item *items, uint32_t cap, uint32_t *n_items, uint32_t *n_lost) {
+    if (!h || !n_items) return fail(KNG_E_ARG, "null argument");
+    *n_items = 0;
+    if (n_lost) *n_lost = 0;
+    if (!items && cap) return fail(KNG_E_ARG, "null items with room for %u", cap);
+    uint32_t found = 0, lost = 0;
+    const int rc = land_points(h, cap, &found, &lost);
+    if (rc != KNG_OK) return rc;
+    for (uint32_t i = 0; i < found; i++) {
+        memcpy(items[i].x, h->h_items[i].x, 32);
+        items[i].d[0] = h->h_items[i].d[0];
+        items[i].d[1] = h->h_items[i].d[1];
+        items[i].kidx = h->h_items[i].kidx;
     }
     *n_items = found;
     if (n_lost) *n_lost = lost;
-    h->slot_ready = -1; // drained
+    return KNG_OK;
+}
+
+static_assert(sizeof(kng_dp_record) == sizeof(DpRecord), "kng_dp_record is the record the kernel writes");
+
+int kng_drain_view(kng_engine *h, const kng_dp_record **records, uint32_t *n_items, uint32_t *n_lost) {
+    if (!h || !records || !n_items) return fail(KNG_E_ARG, "null argument");
+    *records = reinterpret_cast<const kng_dp_record *>(h->h_items);
+    *n_items = 0;
+    if (n_lost) *n_lost = 0;
+    uint32_t found = 0, lost = 0;
+    const int rc = land_points(h, h->max_found, &found, &lost);
+    if (rc != KNG_OK) return rc;
+    *n_items = found;
+    if (n_lost) *n_lost = lost;
     return KNG_OK;
 }
 

@@ -1,40 +1,122 @@
 // kng_dptable.cpp -- see kng_dptable.h.  Product code (host, no GPU needed).
+//
+// Storage.  A bucket of the file format (18 bits of x.limb2) is kept sorted by (x.limb1, x.limb0).  Eight GPUs at the
+// DP size the reference suggests for them deliver ~85 M points per second and 2^30 points per solved 80-bit key:
+// 4096 entries per bucket, where inserting into ONE sorted array would move 64 KB per point.  Each bucket is
+// therefore a row of 2^k "fine" arrays selected by the TOP k bits of x.limb1 -- the most significant bits of the sort
+// key, so the fine arrays, read in index order, ARE the sorted bucket -- and k grows by 2 whenever the bucket holds
+// more than 32 entries per fine array (a local re-split by the one thread that owns the bucket).  An insertion then
+// moves ~0.3 KB whatever the size of the table; the serialised form is unchanged.
 #include "kng_dptable.h"
+
+#include <sys/stat.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "kng_host.h"
 
 namespace {
 
-struct Bucket {
+struct Fine {
     kngt_entry *e = nullptr;
-    uint32_t n = 0;       // entries stored (nbItem)
-    uint32_t cap = 0;     // entries allocated
+    uint32_t n = 0, cap = 0;
+};
+
+struct Bucket {
+    Fine *fine = nullptr; // 1 << k arrays, ordered by the top k bits of x[1]
+    uint32_t n = 0;       // entries in the whole bucket (nbItem)
     uint32_t ref_max = 0; // the reference's maxItem bookkeeping (file compatibility only)
+    uint8_t k = 0;
 };
 
 constexpr uint64_t D_MASK = 0x3FFFFFFFFFFFFFFFULL;
 constexpr uint64_t D_SIGN = 1ULL << 63, D_TYPE = 1ULL << 62;
+constexpr uint32_t SPLIT_AVG = 32; // entries per fine array that trigger a re-split
+constexpr uint8_t K_MAX = 24;
 
 inline int cmp_x(const uint64_t a[2], const uint64_t b[2]) {
     if (a[1] != b[1]) return a[1] > b[1] ? 1 : -1;
     if (a[0] != b[0]) return a[0] > b[0] ? 1 : -1;
     return 0;
 }
+inline size_t fine_index(uint8_t k, uint64_t x1) { return k ? (size_t)(x1 >> (64 - k)) : 0; }
 
-bool reserve(Bucket &b, uint32_t want) {
-    if (want <= b.cap) return true;
-    uint32_t cap = b.cap ? b.cap : 8;
+bool reserve(Fine &f, uint32_t want) {
+    if (want <= f.cap) return true;
+    uint64_t cap = f.cap ? f.cap : 4;
     while (cap < want) cap += cap / 2 + 4;
-    void *p = std::realloc(b.e, (size_t)cap * sizeof(kngt_entry));
+    if (cap > 0xFFFFFFFFULL) return false;
+    void *p = std::realloc(f.e, (size_t)cap * sizeof(kngt_entry));
     if (!p) return false;
-    b.e = static_cast<kngt_entry *>(p);
-    b.cap = cap;
+    f.e = static_cast<kngt_entry *>(p);
+    f.cap = (uint32_t)cap;
     return true;
+}
+
+void free_bucket(Bucket &b) {
+    if (b.fine) {
+        const size_t nf = (size_t)1 << b.k;
+        for (size_t i = 0; i < nf; i++) std::free(b.fine[i].e);
+        std::free(b.fine);
+    }
+    b = Bucket();
+}
+
+// lay `n` entries (sorted) out over 1 << k fine arrays; the bucket must be empty of storage
+bool build(Bucket &b, uint8_t k, const kngt_entry *sorted, uint32_t n) {
+    const size_t nf = (size_t)1 << k;
+    Fine *fine = static_cast<Fine *>(std::calloc(nf, sizeof(Fine)));
+    if (!fine) return false;
+    uint32_t i = 0;
+    while (i < n) {
+        const size_t fi = fine_index(k, sorted[i].x[1]);
+        uint32_t j = i + 1;
+        while (j < n && fine_index(k, sorted[j].x[1]) == fi) j++;
+        Fine &f = fine[fi];
+        if (!reserve(f, j - i + 2)) {
+            for (size_t q = 0; q < nf; q++) std::free(fine[q].e);
+            std::free(fine);
+            return false;
+        }
+        std::memcpy(f.e, sorted + i, (size_t)(j - i) * sizeof(kngt_entry));
+        f.n = j - i;
+        i = j;
+    }
+    b.fine = fine;
+    b.k = k;
+    return true;
+}
+
+// all entries of the bucket, in order
+void gather(const Bucket &b, kngt_entry *out) {
+    if (!b.fine) return;
+    const size_t nf = (size_t)1 << b.k;
+    for (size_t i = 0; i < nf; i++) {
+        if (b.fine[i].n) std::memcpy(out, b.fine[i].e, (size_t)b.fine[i].n * sizeof(kngt_entry));
+        out += b.fine[i].n;
+    }
+}
+
+bool resplit(Bucket &b, uint8_t k) {
+    std::vector<kngt_entry> all(b.n);
+    gather(b, all.data());
+    Bucket nb;
+    if (!build(nb, k, all.data(), b.n)) return false; // keep the old layout: still correct, only slower
+    nb.n = b.n;
+    nb.ref_max = b.ref_max;
+    free_bucket(b);
+    b = nb;
+    return true;
+}
+
+uint8_t k_for(uint32_t n) {
+    uint8_t k = 0;
+    while (k < K_MAX && n > ((SPLIT_AVG / 2) << k)) k += 2;
+    return k;
 }
 
 } // namespace
@@ -49,10 +131,7 @@ kngt_table *kngt_create(void) { return new (std::nothrow) kngt_table(); }
 
 void kngt_reset(kngt_table *t) {
     if (!t) return;
-    for (Bucket &b : t->b) {
-        std::free(b.e);
-        b = Bucket();
-    }
+    for (Bucket &b : t->b) free_bucket(b);
 }
 
 void kngt_destroy(kngt_table *t) {
@@ -80,6 +159,28 @@ void kngt_encode(const uint64_t x[4], const uint64_t d_true[4], uint32_t type, u
     *bucket = (uint32_t)(x[2] & (KNGT_BUCKETS - 1));
 }
 
+void kngt_encode_device(const uint64_t x[4], const uint64_t d_dev[2], const uint64_t wild_offset[2], uint64_t kidx,
+                        uint32_t *bucket, kngt_entry *e) {
+    typedef unsigned __int128 u128;
+    const uint64_t type = kidx & 1;
+    u128 d = ((u128)d_dev[1] << 64) | d_dev[0];
+    uint64_t sign = 0;
+    if (type) { // (d - offset) mod n is "negative" exactly when d < offset; its magnitude is then offset - d
+        const u128 off = ((u128)wild_offset[1] << 64) | wild_offset[0];
+        if (d >= off) {
+            d -= off;
+        } else {
+            d = off - d;
+            sign = D_SIGN;
+        }
+    }
+    e->x[0] = x[0];
+    e->x[1] = x[1];
+    e->d[0] = (uint64_t)d;
+    e->d[1] = ((uint64_t)(d >> 64) & D_MASK) | sign | (type << 62);
+    *bucket = (uint32_t)(x[2] & (KNGT_BUCKETS - 1));
+}
+
 void kngt_decode(const uint64_t d_word[2], uint64_t d_true[4], uint32_t *type) {
     if (type) *type = (d_word[1] & D_TYPE) ? 1 : 0;
     uint64_t v[4] = {d_word[0], d_word[1] & D_MASK, 0, 0};
@@ -91,35 +192,54 @@ void kngt_decode(const uint64_t d_word[2], uint64_t d_true[4], uint32_t *type) {
     }
 }
 
+void kngt_prefetch(const kngt_table *t, uint32_t h, uint64_t x1, int stage) {
+    const Bucket &b = t->b[h & (KNGT_BUCKETS - 1)];
+    if (stage == 0) {
+        __builtin_prefetch(&b);
+    } else if (b.fine) {
+        const Fine *f = &b.fine[fine_index(b.k, x1)];
+        if (stage == 1) {
+            __builtin_prefetch(f);
+        } else if (f->e) { // the whole run: the search reads a few of its lines, the insertion shifts the rest
+            const char *p = reinterpret_cast<const char *>(f->e), *end = p + (size_t)(f->n + 1) * sizeof(kngt_entry);
+            for (int i = 0; i < 12 && p < end; i++, p += 64) __builtin_prefetch(p, 1);
+        }
+    }
+}
+
 int kngt_add_entry(kngt_table *t, uint32_t h, const kngt_entry *e, kngt_entry *other) {
     Bucket &b = t->b[h & (KNGT_BUCKETS - 1)];
     // the reference's allocation bookkeeping, reproduced for the file format: first use -> 16, and a
     // +4 step whenever the bucket is within one slot of full at the START of an add (even one that
     // ends as DUPLICATE/COLLISION)
     if (b.ref_max == 0) b.ref_max = 16;
-    if (b.n == 0) {
-        if (!reserve(b, 1)) return -1;
-        b.e[0] = *e;
-        b.n = 1;
-        return KNGT_ADD_OK;
+    if (!b.fine) {
+        Bucket nb;
+        if (!build(nb, 0, nullptr, 0)) return -1;
+        b.fine = nb.fine;
+        b.k = 0;
     }
-    if (b.n >= b.ref_max - 1) b.ref_max += 4;
+    if (b.n && b.n >= b.ref_max - 1) b.ref_max += 4;
 
-    uint32_t lo = 0, hi = b.n; // first position with x >= e->x
+    Fine &f = b.fine[fine_index(b.k, e->x[1])];
+    uint32_t lo = 0, hi = f.n; // first position with x >= e->x
     while (lo < hi) {
         const uint32_t mid = lo + (hi - lo) / 2;
-        if (cmp_x(b.e[mid].x, e->x) < 0) lo = mid + 1;
+        if (cmp_x(f.e[mid].x, e->x) < 0) lo = mid + 1;
         else hi = mid;
     }
-    if (lo < b.n && cmp_x(b.e[lo].x, e->x) == 0) {
-        if (b.e[lo].d[0] == e->d[0] && b.e[lo].d[1] == e->d[1]) return KNGT_ADD_DUPLICATE;
-        if (other) *other = b.e[lo];
+    if (lo < f.n && cmp_x(f.e[lo].x, e->x) == 0) {
+        if (f.e[lo].d[0] == e->d[0] && f.e[lo].d[1] == e->d[1]) return KNGT_ADD_DUPLICATE;
+        if (other) *other = f.e[lo];
         return KNGT_ADD_COLLISION;
     }
-    if (!reserve(b, b.n + 1)) return -1;
-    std::memmove(b.e + lo + 1, b.e + lo, (size_t)(b.n - lo) * sizeof(kngt_entry));
-    b.e[lo] = *e;
+    if (b.n == 0xFFFFFFFFu) return -1; // nbItem is a 32-bit word of the file format
+    if (!reserve(f, f.n + 1)) return -1;
+    std::memmove(f.e + lo + 1, f.e + lo, (size_t)(f.n - lo) * sizeof(kngt_entry));
+    f.e[lo] = *e;
+    f.n++;
     b.n++;
+    if (b.k < K_MAX && b.n > (SPLIT_AVG << b.k)) (void)resplit(b, (uint8_t)(b.k + 2));
     return KNGT_ADD_OK;
 }
 
@@ -143,33 +263,67 @@ uint32_t kngt_bucket_count(const kngt_table *t, uint32_t bucket) { return t->b[b
 
 uint32_t kngt_bucket_entries(const kngt_table *t, uint32_t bucket, kngt_entry *out, uint32_t cap) {
     const Bucket &b = t->b[bucket & (KNGT_BUCKETS - 1)];
-    const uint32_t n = b.n < cap ? b.n : cap;
-    if (n) std::memcpy(out, b.e, (size_t)n * sizeof(kngt_entry));
-    return n;
+    if (b.n <= cap) {
+        gather(b, out);
+        return b.n;
+    }
+    std::vector<kngt_entry> all(b.n);
+    gather(b, all.data());
+    if (cap) std::memcpy(out, all.data(), (size_t)cap * sizeof(kngt_entry));
+    return cap;
 }
 
 uint64_t kngt_serialised_size(const kngt_table *t) { return (uint64_t)KNGT_BUCKETS * 8 + kngt_count(t) * 32; }
+
+uint64_t kngt_memory_bytes(const kngt_table *t) {
+    uint64_t m = sizeof(kngt_table);
+    for (const Bucket &b : t->b) {
+        if (!b.fine) continue;
+        const size_t nf = (size_t)1 << b.k;
+        m += nf * sizeof(Fine);
+        for (size_t i = 0; i < nf; i++) m += (uint64_t)b.fine[i].cap * sizeof(kngt_entry);
+    }
+    return m;
+}
 
 int kngt_write(const kngt_table *t, FILE *f) {
     for (const Bucket &b : t->b) {
         const uint32_t head[2] = {b.n, b.ref_max};
         if (std::fwrite(head, 4, 2, f) != 2) return -1;
-        if (b.n && std::fwrite(b.e, sizeof(kngt_entry), b.n, f) != b.n) return -1;
+        if (!b.fine) continue;
+        const size_t nf = (size_t)1 << b.k;
+        for (size_t i = 0; i < nf; i++)
+            if (b.fine[i].n && std::fwrite(b.fine[i].e, sizeof(kngt_entry), b.fine[i].n, f) != b.fine[i].n) return -1;
     }
     return 0;
 }
 
 int kngt_read(kngt_table *t, FILE *f) {
     kngt_reset(t);
+    // a bucket cannot announce more entries than the file has bytes left (a truncated or corrupt file must fail,
+    // not allocate); unknown size (a pipe) falls back to the 32-bit word itself
+    uint64_t remaining = UINT64_MAX;
+    struct stat sb;
+    const off_t pos = ftello(f);
+    if (pos >= 0 && fstat(fileno(f), &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size >= (uint64_t)pos)
+        remaining = (uint64_t)sb.st_size - (uint64_t)pos;
+    std::vector<kngt_entry> buf;
     for (Bucket &b : t->b) {
         uint32_t head[2];
         if (std::fread(head, 4, 2, f) != 2) return -1;
+        if (remaining != UINT64_MAX) remaining -= remaining < 8 ? remaining : 8;
+        const uint32_t n = head[0];
+        if ((uint64_t)n * sizeof(kngt_entry) > remaining) return -1;
         b.ref_max = head[1];
-        if (head[0]) {
-            if (!reserve(b, head[0])) return -1;
-            if (std::fread(b.e, sizeof(kngt_entry), head[0], f) != head[0]) return -1;
-            b.n = head[0];
-        }
+        if (!n) continue;
+        buf.resize(n);
+        if (std::fread(buf.data(), sizeof(kngt_entry), n, f) != n) return -1;
+        if (remaining != UINT64_MAX) remaining -= (uint64_t)n * sizeof(kngt_entry);
+        // Add() binary-searches the bucket: it must be strictly ascending in (x.limb1, x.limb0) as the reference writes it
+        for (uint32_t i = 1; i < n; i++)
+            if (cmp_x(buf[i - 1].x, buf[i].x) >= 0) return -1;
+        if (!build(b, k_for(n), buf.data(), n)) return -1;
+        b.n = n;
     }
     return 0;
 }

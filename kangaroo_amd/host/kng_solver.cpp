@@ -9,6 +9,7 @@
 #include <cstring>
 #include <deque>
 #include <mutex>
+#include <random>
 #include <string>
 #include <thread>
 #include <vector>
@@ -77,6 +78,7 @@ struct Consumer {
     std::condition_variable cv;
     std::deque<std::vector<DpMsg>> q;
     std::thread th;
+    std::atomic<uint64_t> handled{0}; // points taken off the queue (load balance across consumers)
 };
 
 struct Worker {
@@ -90,6 +92,7 @@ struct Worker {
     std::atomic<uint64_t> kernel_us_sum{0}; // walk-kernel time of all launches, microseconds
     bool ended = false, paused = false; // guarded by kngs_solver::ctl_m
     uint64_t reset_seq = 0;
+    std::vector<std::vector<DpMsg>> out; // per-consumer batches being filled by ingest()
 };
 
 } // namespace
@@ -107,6 +110,8 @@ struct kngs_solver {
     std::vector<Worker *> workers;
     std::vector<Consumer *> consumers;
     std::atomic<uint64_t> inflight{0}; // DP messages queued but not yet in the table
+    std::mutex pool_m;
+    std::vector<std::vector<DpMsg>> pool; // emptied batch buffers on their way back to the GPU threads
 
     // control
     std::mutex ctl_m;
@@ -128,15 +133,18 @@ struct kngs_solver {
     // restored herds
     kngw_file *herd_file = nullptr;
     uint64_t herd_left = 0;
+    uint64_t herd_loaded = 0, herd_created = 0;
+    uint64_t seed_used = 0;
+    bool ingest_only = false; // kngs_start_ingest: consumers without engines (host-path measurements)
 };
 
 namespace {
 
+// the flags are part of the predicates kngs_wait / the parked workers sleep on: change them under ctl_m, or a
+// waiter that has just evaluated its predicate misses the notification
 void set_error(kngs_solver *s, const std::string &msg) {
-    {
-        std::lock_guard<std::mutex> g(s->ctl_m);
-        if (s->error.empty()) s->error = msg;
-    }
+    std::lock_guard<std::mutex> g(s->ctl_m);
+    if (s->error.empty()) s->error = msg;
     s->failed = true;
     s->stop = true;
     s->ctl_cv.notify_all();
@@ -175,7 +183,14 @@ void consumer_main(kngs_solver *s, Consumer *c) {
             batch.swap(c->q.front());
             c->q.pop_front();
         }
-        for (const DpMsg &m : batch) {
+        c->handled += batch.size();
+        const size_t nb = batch.size();
+        for (size_t bi = 0; bi < nb; bi++) {
+            // the table is far larger than the caches: touch bucket header, run header and run a few points ahead
+            if (bi + 12 < nb) kngt_prefetch(s->table, batch[bi + 12].bucket, batch[bi + 12].e.x[1], 0);
+            if (bi + 8 < nb) kngt_prefetch(s->table, batch[bi + 8].bucket, batch[bi + 8].e.x[1], 1);
+            if (bi + 4 < nb) kngt_prefetch(s->table, batch[bi + 4].bucket, batch[bi + 4].e.x[1], 2);
+            const DpMsg &m = batch[bi];
             if (s->solved) break;
             kngt_entry other;
             const int st = kngt_add_entry(s->table, m.bucket, &m.e, &other);
@@ -197,10 +212,10 @@ void consumer_main(kngs_solver *s, Consumer *c) {
                         {
                             std::lock_guard<std::mutex> g(s->ctl_m);
                             std::memcpy(s->priv, priv, 32);
+                            s->solved = true;
+                            s->stop = true;
+                            s->ctl_cv.notify_all();
                         }
-                        s->solved = true;
-                        s->stop = true;
-                        s->ctl_cv.notify_all();
                         replace = false;
                     } else {
                         s->wrong++;
@@ -213,6 +228,9 @@ void consumer_main(kngs_solver *s, Consumer *c) {
             }
         }
         s->inflight -= batch.size();
+        batch.clear();
+        std::lock_guard<std::mutex> g(s->pool_m);
+        if (s->pool.size() < 4 * s->consumers.size() * (s->workers.size() + 1)) s->pool.emplace_back(std::move(batch));
     }
 }
 
@@ -220,7 +238,7 @@ void consumer_main(kngs_solver *s, Consumer *c) {
 int replace_kangaroo(kngs_solver *s, Worker *w, uint64_t kidx) {
     uint64_t x[4], y[4], d[4], dd[4];
     const int type = (int)(kidx & 1);
-    const uint64_t seed = s->cfg.seed ^ (0x9E3779B97F4A7C15ULL * (++w->reset_seq)) ^ ((uint64_t)w->index << 56) ^ kidx;
+    const uint64_t seed = s->seed_used ^ (0x9E3779B97F4A7C15ULL * (++w->reset_seq)) ^ ((uint64_t)w->index << 56) ^ kidx;
     if (kngh_create_herd(1, s->range_power, s->wild_offset.v, s->skx, s->sky, type, seed, 1, x, y, d) != 0)
         return fail("kngh_create_herd failed");
     if (type) kngh_add_order(d, s->wild_offset.v, dd); else std::memcpy(dd, d, 32);
@@ -229,12 +247,57 @@ int replace_kangaroo(kngs_solver *s, Worker *w, uint64_t kidx) {
     return 0;
 }
 
-void worker_main(kngs_solver *s, Worker *w) {
-    const uint32_t cap = s->cfg.max_found;
-    std::vector<kng_item> items(cap);
-    std::vector<uint64_t> ddev, kidx, dtrue;
+// The distinguished points of one launch, straight from the engine's pinned records: one pass turns each record
+// into its table entry (GPUEngine.cu:672 + HashTable::Convert in one step) and appends it to the batch of the
+// consumer that owns its bucket (the c-th of nc equal ranges of a scrambled bucket index: two multiplies, no division).
+// Batch buffers come back from the consumers through a pool, so a launch touches no fresh pages.  At the 8-GPU DP
+// size (262 144 points per 25 ms launch) this must stay well under 95 ns per point: tools/dp_ingest_bench.
+inline size_t consumer_of(uint32_t bucket, size_t nc) {
+    const uint32_t h = (bucket * 0x9E3779B1u) & (KNGT_BUCKETS - 1); // a bijection of the 18-bit bucket index that spreads neighbours
+    return ((size_t)h * nc) >> KNGT_HASH_BITS;
+}
+
+void ingest(kngs_solver *s, Worker *w, const kng_dp_record *rec, uint32_t n) {
     const size_t nc = s->consumers.size();
-    std::vector<std::vector<DpMsg>> out(nc);
+    if (w->out.size() != nc) w->out.resize(nc);
+    const size_t want = n / nc + n / (4 * nc) + 64; // a consumer's share, with room for the spread
+    for (size_t c = 0; c < nc; c++) {
+        std::vector<DpMsg> &v = w->out[c];
+        if (v.capacity() < want) {
+            std::vector<DpMsg> spare;
+            {
+                std::lock_guard<std::mutex> g(s->pool_m);
+                if (!s->pool.empty()) {
+                    spare.swap(s->pool.back());
+                    s->pool.pop_back();
+                }
+            }
+            if (spare.capacity() > v.capacity()) v.swap(spare);
+            v.clear();
+            v.reserve(want);
+        }
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        DpMsg m;
+        kngt_encode_device(rec[i].x, rec[i].d, s->wild_offset.v, rec[i].kidx, &m.bucket, &m.e);
+        m.gpu = (uint32_t)w->index;
+        m.kidx = rec[i].kidx;
+        w->out[consumer_of(m.bucket, nc)].push_back(m);
+    }
+    for (size_t c = 0; c < nc; c++) {
+        if (w->out[c].empty()) continue;
+        s->inflight += w->out[c].size();
+        Consumer *cs = s->consumers[c];
+        {
+            std::lock_guard<std::mutex> g(cs->m);
+            cs->q.emplace_back(std::move(w->out[c]));
+        }
+        cs->cv.notify_one();
+        w->out[c] = std::vector<DpMsg>();
+    }
+}
+
+void worker_main(kngs_solver *s, Worker *w) {
     auto bail = [&](const std::string &msg) {
         set_error(s, msg);
         std::lock_guard<std::mutex> g(s->ctl_m);
@@ -255,39 +318,11 @@ void worker_main(kngs_solver *s, Worker *w) {
         if (go_on && kng_launch(w->eng) != KNG_OK) return bail(std::string("kng_launch: ") + kng_last_error());
 
         uint32_t n_items = 0, n_lost = 0;
-        if (kng_drain(w->eng, items.data(), cap, &n_items, &n_lost) != KNG_OK) return bail(std::string("kng_drain: ") + kng_last_error());
+        const kng_dp_record *rec = nullptr;
+        if (kng_drain_view(w->eng, &rec, &n_items, &n_lost) != KNG_OK) return bail(std::string("kng_drain_view: ") + kng_last_error());
         s->dps += n_items;
         s->dps_lost += n_lost;
-        if (n_items) {
-            ddev.resize((size_t)n_items * 2);
-            kidx.resize(n_items);
-            dtrue.resize((size_t)n_items * 4);
-            for (uint32_t i = 0; i < n_items; i++) {
-                ddev[2 * i] = items[i].d[0];
-                ddev[2 * i + 1] = items[i].d[1];
-                kidx[i] = items[i].kidx;
-            }
-            // GPUEngine.cu:672: wild distances leave the engine with the offset still added
-            kngh_to_true_distances(ddev.data(), kidx.data(), n_items, s->wild_offset.v, dtrue.data());
-            for (uint32_t i = 0; i < n_items; i++) {
-                DpMsg m;
-                kngt_encode(items[i].x, &dtrue[4 * (size_t)i], (uint32_t)(items[i].kidx & 1), &m.bucket, &m.e);
-                m.gpu = (uint32_t)w->index;
-                m.kidx = items[i].kidx;
-                out[m.bucket % nc].push_back(m);
-            }
-            for (size_t c = 0; c < nc; c++) {
-                if (out[c].empty()) continue;
-                s->inflight += out[c].size();
-                Consumer *cs = s->consumers[c];
-                {
-                    std::lock_guard<std::mutex> g(cs->m);
-                    cs->q.emplace_back(std::move(out[c]));
-                }
-                cs->cv.notify_one();
-                out[c].clear();
-            }
-        }
+        if (n_items) ingest(s, w, rec, n_items);
         // kangaroos the consumers asked to replace; stream-ordered behind the launch in flight
         std::vector<uint64_t> todo;
         {
@@ -319,19 +354,20 @@ void worker_main(kngs_solver *s, Worker *w) {
     }
 }
 
-// upload `n` kangaroos of worker w from the open work file, in chunks
-int upload_from_file(kngs_solver *s, Worker *w) {
+// upload the first `count` kangaroos of worker w from the open work file, in chunks
+int upload_from_file(kngs_solver *s, Worker *w, uint64_t count) {
     const uint64_t C = 1u << 16;
     std::vector<uint64_t> x(C * 4), y(C * 4), d(C * 4), dd(C * 2);
-    for (uint64_t c0 = 0; c0 < w->n; c0 += C) {
-        const uint64_t m = w->n - c0 < C ? w->n - c0 : C;
+    for (uint64_t c0 = 0; c0 < count; c0 += C) {
+        const uint64_t m = count - c0 < C ? count - c0 : C;
         if (kngw_get_kangaroos(s->herd_file, x.data(), y.data(), d.data(), m) != 0) return fail("%s", kngw_last_error());
         // device distances: odd (wild) indices carry +wildOffset mod n (GPUEngine.cu:406-411); c0 is even
         if (kngh_to_device_distances(d.data(), m, s->wild_offset.v, dd.data()) != 0) return fail("restored distance does not fit 128 bits");
         if (kng_set_kangaroos_range(w->eng, c0, m, x.data(), 4, y.data(), 4, dd.data(), 2) != KNG_OK)
             return fail("kng_set_kangaroos_range: %s", kng_last_error());
     }
-    s->herd_left -= w->n;
+    s->herd_left -= count;
+    s->herd_loaded += count;
     return 0;
 }
 
@@ -456,10 +492,41 @@ int kngs_load(kngs_solver *s, const char *path) {
     return 0;
 }
 
+namespace {
+
+// everything kngs_start and kngs_start_ingest share: consumers, clock, state
+void start_consumers(kngs_solver *s, int nc) {
+    for (int c = 0; c < nc; c++) s->consumers.push_back(new Consumer());
+    s->t_start = Clock::now();
+    s->started = true;
+    for (Consumer *c : s->consumers) c->th = std::thread(consumer_main, s, c);
+}
+
+uint64_t draw_seed() {
+    std::random_device rd; // the reference seeds from the clock (Timer::getSeed32, main.cpp:177)
+    uint64_t v = ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ (uint64_t)Clock::now().time_since_epoch().count();
+    return v ? v : 1;
+}
+
+} // namespace
+
 int kngs_start(kngs_solver *s) {
     if (!s) return fail("null argument");
     if (s->started) return fail("already started");
     const kngs_config &cfg = s->cfg;
+    // a failed start leaves the solver as it was before the call: no half-built workers to trip a second attempt
+    auto undo = [&](int rc) {
+        for (Worker *w : s->workers) {
+            if (w->eng) kng_destroy(w->eng);
+            delete w;
+        }
+        s->workers.clear();
+        s->herd_loaded = s->herd_created = 0;
+        return rc;
+    };
+    // seed 0 = draw one: two runs (or a resumed run) must not rebuild the same herds -- their walks would retrace
+    // trails already in the table and every point would come back as a duplicate
+    s->seed_used = cfg.seed ? cfg.seed : draw_seed();
     uint64_t total = 0;
     for (int g = 0; g < cfg.n_gpus; g++) {
         Worker *w = new Worker();
@@ -467,15 +534,13 @@ int kngs_start(kngs_solver *s) {
         w->dev = cfg.gpu_ids[g];
         w->grid_x = cfg.grid_x;
         w->grid_y = cfg.grid_y;
+        s->workers.push_back(w);
         if (w->grid_x <= 0 || w->grid_y <= 0) {
-            if (kng_default_grid(w->dev, &w->grid_x, &w->grid_y) != KNG_OK) {
-                delete w;
-                return fail("kng_default_grid(%d): %s", cfg.gpu_ids[g], kng_last_error());
-            }
+            if (kng_default_grid(w->dev, &w->grid_x, &w->grid_y) != KNG_OK)
+                return undo(fail("kng_default_grid(%d): %s", cfg.gpu_ids[g], kng_last_error()));
         }
         w->n = (uint64_t)w->grid_x * (uint64_t)w->grid_y * KNG_GRP_SIZE;
         total += w->n;
-        s->workers.push_back(w);
     }
     // Run (Kangaroo.cpp:974-993): suggested DP size for the whole population
     s->dp = cfg.dp >= 0 ? cfg.dp : kngh_suggest_dp(s->range_power, (double)total);
@@ -492,36 +557,101 @@ int kngs_start(kngs_solver *s) {
     }
     for (Worker *w : s->workers) {
         if (kng_create(w->dev, w->grid_x, w->grid_y, s->cfg.max_found, &w->eng) != KNG_OK)
-            return fail("kng_create(gpu %d): %s", w->dev, kng_last_error());
-        if (kng_set_params(w->eng, s->dp_mask, s->jd, s->jx, s->jy) != KNG_OK) return fail("kng_set_params: %s", kng_last_error());
-        if (s->herd_file && s->herd_left >= w->n) {
-            if (upload_from_file(s, w) != 0) return -1;
-        } else {
+            return undo(fail("kng_create(gpu %d): %s", w->dev, kng_last_error()));
+        if (kng_set_params(w->eng, s->dp_mask, s->jd, s->jx, s->jy) != KNG_OK) return undo(fail("kng_set_params: %s", kng_last_error()));
+        // FetchWalks (Kangaroo.cpp:646-668): take what the file still holds, create the rest
+        const uint64_t from_file = s->herd_file ? (s->herd_left < w->n ? s->herd_left : w->n) : 0;
+        if (from_file < w->n) {
             // herd built on the device (kng_build_herd); each GPU gets its own stream of distances
             const uint32_t windows = (uint32_t)(s->range_power + 7) / 8;
             std::vector<uint64_t> table((size_t)windows * 256 * 8);
             uint64_t bt[8], bw[8], fin[8];
-            const uint64_t seed = cfg.seed + 0x51ED270B1ULL * (uint64_t)(w->index + 1);
+            const uint64_t seed = s->seed_used + 0x51ED270B1ULL * (uint64_t)(w->index + 1);
             if (kngh_herd_params(s->range_power, s->wild_offset.v, s->skx, s->sky, seed, table.data(), bt, bw, fin) != 0)
-                return fail("kngh_herd_params failed");
+                return undo(fail("kngh_herd_params failed"));
             if (kng_build_herd(w->eng, s->range_power, seed, table.data(), windows, bt, bw, fin) != KNG_OK)
-                return fail("kng_build_herd: %s", kng_last_error());
+                return undo(fail("kng_build_herd: %s", kng_last_error()));
+            s->herd_created += w->n - from_file;
         }
+        // restored kangaroos overwrite the head of the herd (even start index: types stay aligned with parity)
+        if (from_file && upload_from_file(s, w, from_file) != 0) return undo(-1);
     }
     if (s->herd_file) {
         kngw_close(s->herd_file);
         s->herd_file = nullptr;
     }
-    // one table thread sustains several million inserts per second; a GPU emits ~1.3 M DPs/s at the suggested DP
-    // size alone and proportionally more when the population grows (the suggestion shrinks with log2 of it)
-    int nc = cfg.consumers > 0 ? cfg.consumers : (cfg.n_gpus == 1 ? 1 : (2 * cfg.n_gpus > 16 ? 16 : 2 * cfg.n_gpus));
-    for (int c = 0; c < nc; c++) s->consumers.push_back(new Consumer());
-    s->t_start = Clock::now();
-    s->started = true;
-    for (Consumer *c : s->consumers) c->th = std::thread(consumer_main, s, c);
+    // one table thread sustains 2-5 M inserts per second depending on the table size (tools/dp_ingest_bench); one GPU
+    // emits 1.3 M points/s at its own suggested DP size, eight GPUs 85 M/s at theirs (the suggestion shrinks with the
+    // population, Kangaroo.cpp:980-993): six threads per GPU, within half of the host's hardware threads
+    int nc = cfg.consumers;
+    if (nc <= 0) {
+        const int hw = (int)std::thread::hardware_concurrency();
+        nc = cfg.n_gpus == 1 ? 1 : 6 * cfg.n_gpus;
+        if (hw > 0 && nc > hw / 2) nc = hw / 2;
+        if (nc > 64) nc = 64;
+        if (nc < 2 && cfg.n_gpus > 1) nc = 2;
+        if (nc < 1) nc = 1;
+    }
+    start_consumers(s, nc);
     for (Worker *w : s->workers) w->th = std::thread(worker_main, s, w);
     return 0;
 }
+
+int kngs_start_ingest(kngs_solver *s, int feeders) {
+    if (!s) return fail("null argument");
+    if (s->started) return fail("already started");
+    if (feeders < 1 || feeders > 256) return fail("feeders must be 1..256");
+    s->ingest_only = true;
+    s->seed_used = s->cfg.seed ? s->cfg.seed : draw_seed();
+    for (int g = 0; g < feeders; g++) {
+        Worker *w = new Worker();
+        w->index = g;
+        w->ended = true; // no GPU thread behind it
+        s->workers.push_back(w);
+    }
+    start_consumers(s, s->cfg.consumers > 0 ? s->cfg.consumers : (2 * feeders > 16 ? 16 : 2 * feeders));
+    return 0;
+}
+
+int kngs_ingest(kngs_solver *s, int feeder, const kng_dp_record *records, uint32_t n) {
+    if (!s || (!records && n)) return fail("null argument");
+    if (!s->ingest_only || !s->started || s->joined) return fail("kngs_ingest needs a solver started with kngs_start_ingest");
+    if (feeder < 0 || (size_t)feeder >= s->workers.size()) return fail("no feeder %d", feeder);
+    if (s->failed) return fail("%s", s->error.c_str());
+    s->dps += n;
+    if (n) ingest(s, s->workers[(size_t)feeder], records, n);
+    return 0;
+}
+
+int kngs_drained(kngs_solver *s, double seconds) {
+    if (!s) return fail("null argument");
+    const auto t0 = Clock::now();
+    while (s->inflight.load() && !s->failed) {
+        if (seconds_since(t0) > seconds) return 0;
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    if (s->failed) return fail("%s", s->error.c_str());
+    return 1;
+}
+
+int kngs_consumer_load(const kngs_solver *s, uint64_t *handled, int cap) {
+    if (!s || (!handled && cap)) return fail("null argument");
+    const int n = (int)s->consumers.size();
+    for (int i = 0; i < n && i < cap; i++) handled[i] = s->consumers[(size_t)i]->handled.load();
+    return n;
+}
+
+int kngs_gpu_stats(const kngs_solver *s, int gpu, uint64_t *launches, double *kernel_ms_sum, uint64_t *kangaroos) {
+    if (!s) return fail("null argument");
+    if (gpu < 0 || (size_t)gpu >= s->workers.size()) return fail("no gpu %d", gpu);
+    const Worker *w = s->workers[(size_t)gpu];
+    if (launches) *launches = w->launches.load();
+    if (kernel_ms_sum) *kernel_ms_sum = (double)w->kernel_us_sum.load() * 1e-3;
+    if (kangaroos) *kangaroos = w->n;
+    return 0;
+}
+
+const kngt_table *kngs_table(const kngs_solver *s) { return s ? s->table : nullptr; }
 
 int kngs_wait(kngs_solver *s, double seconds) {
     if (!s) return fail("null argument");
@@ -532,6 +662,8 @@ int kngs_wait(kngs_solver *s, double seconds) {
             if (!w->ended) return false;
         return true;
     };
+    // a huge or infinite timeout would overflow the clock's integer tick count
+    seconds = seconds > 0 ? (seconds < 1e9 ? seconds : 1e9) : 0;
     const auto deadline = Clock::now() + std::chrono::duration_cast<Clock::duration>(std::chrono::duration<double>(seconds));
     while (!s->solved && !s->failed && !all_ended()) {
         if (s->ctl_cv.wait_until(lk, deadline) == std::cv_status::timeout) break;
@@ -551,8 +683,11 @@ int kngs_wait(kngs_solver *s, double seconds) {
 int kngs_stop(kngs_solver *s) {
     if (!s) return fail("null argument");
     if (!s->started) return 0;
-    s->stop = true;
-    s->ctl_cv.notify_all();
+    {
+        std::lock_guard<std::mutex> g(s->ctl_m);
+        s->stop = true;
+        s->ctl_cv.notify_all();
+    }
     join_all(s);
     if (s->failed) return fail("%s", s->error.c_str());
     return 0;
@@ -594,6 +729,11 @@ int kngs_get_stats(const kngs_solver *s, kngs_stats *st) {
     st->range_power = s->range_power;
     st->solved = s->solved ? 1 : 0;
     st->running = s->started && !s->joined ? running : 0;
+    st->seed = s->seed_used;
+    st->herd_loaded = s->herd_loaded;
+    st->herd_created = s->herd_created;
+    st->table_bytes = s->joined || s->ingest_only ? kngt_memory_bytes(s->table) : 0;
+    if (s->ingest_only) st->table_items = kngt_count(s->table); // racy while points are in flight: callers drain first
     return 0;
 }
 
@@ -608,13 +748,24 @@ int kngs_save(kngs_solver *s, const char *path, int with_kangaroos) {
     std::lock_guard<std::mutex> save_lock(s->save_m);
     // SaveWork (Backup.cpp:446-470): wait until every thread blocks at a launch boundary
     s->pause_req = 1;
+    bool parked;
     {
+        // a launch lasts tens of milliseconds; a worker that has not reached its boundary after two minutes is
+        // stuck in the driver (the reference's SaveWork has the same guard, wtimeout, Backup.cpp:446-470)
         std::unique_lock<std::mutex> lk(s->ctl_m);
-        s->ctl_cv.wait(lk, [&] {
+        parked = s->ctl_cv.wait_for(lk, std::chrono::seconds(120), [&] {
             for (Worker *w : s->workers)
                 if (!w->paused && !w->ended) return false;
             return true;
         });
+    }
+    if (!parked) {
+        {
+            std::lock_guard<std::mutex> g(s->ctl_m);
+            s->pause_req = 0;
+        }
+        s->ctl_cv.notify_all();
+        return fail("timed out waiting for the GPU threads to reach a launch boundary");
     }
     while (s->inflight.load() && !s->failed) std::this_thread::sleep_for(std::chrono::milliseconds(1));
     int rc = 0;

@@ -40,7 +40,9 @@ typedef struct kngs_config {
     int32_t grid_x, grid_y; /* <=0: kng_default_grid of each device */
     uint32_t max_found;     /* DP slots per launch; 0 = max(131072, 2 x expected) */
     int32_t consumers;      /* hash-table threads; 0 = automatic */
-    uint64_t seed;          /* herd seed (the reference seeds from the clock) */
+    uint64_t seed;          /* herd seed; 0 = draw one (the reference seeds from the clock, main.cpp:177). Fix it only
+                               for tests and benchmarks: equal seeds rebuild equal herds, whose walks retrace trails
+                               already in a restored table */
     uint64_t max_launches;  /* per GPU, 0 = until solved or stopped */
 } kngs_config;
 
@@ -56,6 +58,10 @@ typedef struct kngs_stats {
     double seconds;            /* wall time since kngs_start (plus restored time) */
     double kernel_ms_avg;      /* mean walk-kernel duration over GPUs and launches */
     int32_t dp, range_power, solved, running;
+    uint64_t seed;             /* the herd seed in use (drawn when the configuration said 0) */
+    uint64_t herd_loaded;      /* kangaroos taken from the work file at start */
+    uint64_t herd_created;     /* kangaroos created at start (none left in the file for them) */
+    uint64_t table_bytes;      /* memory held by the table (0 while the consumers are running) */
 } kngs_stats;
 
 typedef struct kngs_solver kngs_solver;
@@ -81,6 +87,22 @@ int kngs_save(kngs_solver *s, const char *path, int with_kangaroos);
  * true distances (mod n) of a tame and a wild kangaroo standing on the same point, try the reference's four sign
  * combinations and return the private key (1) or 0 when none reproduces the public key.  No GPU needed. */
 int kngs_collision_key(const kngs_solver *s, const uint64_t tame_d[4], const uint64_t wild_d[4], uint64_t priv[4]);
+/* per-GPU figures of this run: launches done, summed walk-kernel time (HIP events), herd size */
+int kngs_gpu_stats(const kngs_solver *s, int gpu, uint64_t *launches, double *kernel_ms_sum, uint64_t *kangaroos);
+/* points each consumer thread has taken off its queue; returns the number of consumers */
+int kngs_consumer_load(const kngs_solver *s, uint64_t *handled, int cap);
+
+/* ---- the host path without engines: measurements and tests of the DP ingest (no GPU needed) ----
+ * kngs_start_ingest starts only the consumer threads; `feeders` callers (one thread each, distinct feeder ids)
+ * then hand over engine records exactly as a GPU thread would after kng_drain_view.  kngs_drained waits until
+ * every queued point is in the table (1) or `seconds` passed (0).  Stop with kngs_stop. */
+struct kng_dp_record;
+int kngs_start_ingest(kngs_solver *s, int feeders);
+int kngs_ingest(kngs_solver *s, int feeder, const struct kng_dp_record *records, uint32_t n);
+int kngs_drained(kngs_solver *s, double seconds);
+/* the solver's table, read-only (tests; exact only while no point is in flight) */
+struct kngt_table;
+const struct kngt_table *kngs_table(const kngs_solver *s);
 const char *kngs_last_error(void);
 
 #ifdef __cplusplus

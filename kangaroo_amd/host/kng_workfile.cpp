@@ -1,6 +1,8 @@
 // kng_workfile.cpp -- see kng_workfile.h.  Product code (host, no GPU needed).
 #include "kng_workfile.h"
 
+#include <unistd.h>
+
 #include <cerrno>
 #include <cstdarg>
 #include <cstdio>
@@ -30,7 +32,8 @@ struct kngw_file {
     FILE *f = nullptr;
     bool writer = false;
     uint64_t declared = 0, done = 0; // kangaroo section: announced / transferred so far
-    std::string path;
+    std::string path;                // final name
+    std::string tmp;                 // writers: the file being written, renamed over `path` by kngw_close
     std::vector<uint64_t> buf;       // CHUNK x 12 limbs
 };
 
@@ -42,8 +45,11 @@ kngw_file *kngw_create(const char *path, const kngw_header *h, const kngt_table 
     if (!path || !h) return (kngw_file *)fail("null argument");
     if (h->magic != KNGW_HEADW && h->magic != KNGW_HEADK) return (kngw_file *)fail("unknown work file type 0x%08X", h->magic);
     if (h->magic == KNGW_HEADW && !table) return (kngw_file *)fail("a HEADW work file needs a hash table");
-    FILE *f = std::fopen(path, "wb");
-    if (!f) return (kngw_file *)fail("cannot open %s for writing: %s", path, std::strerror(errno));
+    // never write over the previous checkpoint in place: a crash, a full disk or a kill during a periodic save would
+    // destroy days of distinguished points.  Write a sibling, flush it to the disk, then rename it over the target.
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return (kngw_file *)fail("cannot open %s for writing: %s", tmp.c_str(), std::strerror(errno));
     bool ok = std::fwrite(&h->magic, 4, 1, f) == 1 && std::fwrite(&h->version, 4, 1, f) == 1;
     if (ok && h->magic == KNGW_HEADW) {
         ok = std::fwrite(&h->dp_size, 4, 1, f) == 1 && std::fwrite(h->range_start, 32, 1, f) == 1 &&
@@ -53,14 +59,17 @@ kngw_file *kngw_create(const char *path, const kngw_header *h, const kngt_table 
     }
     ok = ok && std::fwrite(&n_kangaroos, 8, 1, f) == 1;
     if (!ok) {
+        const int e = errno;
         std::fclose(f);
-        return (kngw_file *)fail("short write to %s: %s", path, std::strerror(errno));
+        std::remove(tmp.c_str());
+        return (kngw_file *)fail("short write to %s: %s", tmp.c_str(), std::strerror(e));
     }
     kngw_file *w = new kngw_file();
     w->f = f;
     w->writer = true;
     w->declared = n_kangaroos;
     w->path = path;
+    w->tmp = tmp;
     return w;
 }
 
@@ -145,9 +154,20 @@ int kngw_close(kngw_file *w) {
         fail("%s: %llu kangaroos announced, %llu written", w->path.c_str(), (unsigned long long)w->declared, (unsigned long long)w->done);
         rc = -1;
     }
-    if (std::fclose(w->f) != 0 && rc == 0) {
-        fail("closing %s: %s", w->path.c_str(), std::strerror(errno));
+    if (w->writer && rc == 0 && (std::fflush(w->f) != 0 || fsync(fileno(w->f)) != 0)) {
+        fail("flushing %s: %s", w->tmp.c_str(), std::strerror(errno));
         rc = -1;
+    }
+    if (std::fclose(w->f) != 0 && rc == 0) {
+        fail("closing %s: %s", w->writer ? w->tmp.c_str() : w->path.c_str(), std::strerror(errno));
+        rc = -1;
+    }
+    if (w->writer) {
+        if (rc == 0 && std::rename(w->tmp.c_str(), w->path.c_str()) != 0) {
+            fail("renaming %s to %s: %s", w->tmp.c_str(), w->path.c_str(), std::strerror(errno));
+            rc = -1;
+        }
+        if (rc != 0) std::remove(w->tmp.c_str()); // the previous file at `path`, if any, is untouched
     }
     delete w;
     return rc;

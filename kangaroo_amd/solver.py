@@ -44,7 +44,11 @@ class _Stats(C.Structure):
     _fields_ = [("jumps", C.c_uint64), ("launches", C.c_uint64), ("dps", C.c_uint64), ("dps_lost", C.c_uint64),
                 ("same_herd", C.c_uint64), ("wrong_collisions", C.c_uint64), ("table_items", C.c_uint64),
                 ("kangaroos", C.c_uint64), ("seconds", C.c_double), ("kernel_ms_avg", C.c_double), ("dp", C.c_int32),
-                ("range_power", C.c_int32), ("solved", C.c_int32), ("running", C.c_int32)]
+                ("range_power", C.c_int32), ("solved", C.c_int32), ("running", C.c_int32), ("seed", C.c_uint64),
+                ("herd_loaded", C.c_uint64), ("herd_created", C.c_uint64), ("table_bytes", C.c_uint64)]
+
+
+DP_RECORD_DTYPE = np.dtype([("x", np.uint64, (4,)), ("d", np.uint64, (2,)), ("kidx", np.uint64), ("reserved", np.uint64)])
 
 
 _bound = False
@@ -88,6 +92,19 @@ def _lib() -> C.CDLL:
         L.kngs_save.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.kngs_collision_key.argtypes = [C.c_void_p, _U64P, _U64P, _U64P]
         L.kngs_last_error.restype = C.c_char_p
+        L.kngs_gpu_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.kngs_consumer_load.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.kngs_start_ingest.argtypes = [C.c_void_p, C.c_int]
+        L.kngs_ingest.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32]
+        L.kngs_drained.argtypes = [C.c_void_p, C.c_double]
+        L.kngs_table.argtypes = [C.c_void_p]
+        L.kngs_table.restype = C.c_void_p
+        L.kngt_memory_bytes.argtypes = [C.c_void_p]
+        L.kngt_memory_bytes.restype = C.c_uint64
+        L.kngt_encode_device.argtypes = [_U64P, _U64P, _U64P, C.c_uint64, C.POINTER(C.c_uint32), C.c_void_p]
+        L.kngt_encode_device.restype = None
+        L.kngt_encode.argtypes = [_U64P, _U64P, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p]
+        L.kngt_encode.restype = None
         _bound = True
     return L
 
@@ -99,16 +116,20 @@ class HostError(RuntimeError):
 class DpTable:
     """HashTable (HashTable.h:58-100): Add / GetNbItem / Reset + access to the sorted buckets."""
 
-    def __init__(self):
+    def __init__(self, _borrowed=None):
         self._L = _lib()
-        self._h = self._L.kngt_create()
+        self._own = _borrowed is None
+        self._h = self._L.kngt_create() if self._own else _borrowed
         if not self._h:
             raise MemoryError("kngt_create")
 
     def close(self):
-        if self._h:
+        if self._h and self._own:
             self._L.kngt_destroy(self._h)
-            self._h = None
+        self._h = None
+
+    def memory_bytes(self) -> int:
+        return int(self._L.kngt_memory_bytes(self._h))
 
     def __del__(self):
         try:
@@ -191,7 +212,9 @@ class Solver:
     """Kangaroo::SolveKeyGPU for N GPUs (Kangaroo.cpp:510-644, :1019-1063) over the C-ABI engine."""
 
     def __init__(self, range_start: int, range_end: int, key, *, gpus=(0,), grid=(0, 0), dp: int = -1, max_found: int = 0,
-                 consumers: int = 0, seed: int = 1, max_launches: int = 0):
+                 consumers: int = 0, seed: int = 0, max_launches: int = 0):
+        """seed 0 (default) draws a herd seed like the reference does from the clock (main.cpp:177); stats()["seed"]
+        reports it.  Pass a fixed seed only for tests and benchmarks: equal seeds rebuild equal herds."""
         self._L = _lib()
         cfg = _Config(dp=dp, n_gpus=len(gpus), grid_x=grid[0], grid_y=grid[1], max_found=max_found, consumers=consumers,
                       seed=seed & ((1 << 64) - 1), max_launches=max_launches)
@@ -249,6 +272,32 @@ class Solver:
         out = np.zeros(4, np.uint64)
         rc = self._check(self._L.kngs_collision_key(self._h, limbs(tame_d), limbs(wild_d), out))
         return to_int(out) if rc == 1 else None
+
+    def gpu_stats(self, gpu: int) -> dict:
+        """launches, summed kernel milliseconds (HIP events) and herd size of one GPU of this run"""
+        l, ms, n = C.c_uint64(0), C.c_double(0), C.c_uint64(0)
+        self._check(self._L.kngs_gpu_stats(self._h, gpu, C.byref(l), C.byref(ms), C.byref(n)))
+        return {"launches": int(l.value), "kernel_ms_sum": float(ms.value), "kangaroos": int(n.value)}
+
+    def consumer_load(self) -> list:
+        buf = (C.c_uint64 * 64)()
+        n = self._check(self._L.kngs_consumer_load(self._h, buf, 64))
+        return [int(buf[i]) for i in range(min(n, 64))]
+
+    # ---- the host path without engines (kng_solver.h: measurements and tests of the DP ingest) ----
+    def start_ingest(self, feeders: int):
+        self._check(self._L.kngs_start_ingest(self._h, feeders))
+
+    def ingest(self, feeder: int, records: np.ndarray):
+        assert records.dtype == DP_RECORD_DTYPE and records.flags.c_contiguous
+        self._check(self._L.kngs_ingest(self._h, feeder, records.ctypes.data, len(records)))
+
+    def drained(self, seconds: float) -> bool:
+        return self._check(self._L.kngs_drained(self._h, seconds)) == 1
+
+    def table(self) -> "DpTable":
+        """read-only view of the solver's table (exact while no point is in flight)"""
+        return DpTable(_borrowed=self._L.kngs_table(self._h))
 
     def save(self, path: str, with_kangaroos: bool = True):
         self._check(self._L.kngs_save(self._h, path.encode(), 1 if with_kangaroos else 0))

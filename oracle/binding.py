@@ -70,6 +70,9 @@ class Oracle:
                      C.c_void_p, C.c_size_t]
         L.orc_walk.argtypes = walk_args
         L.orc_walk.restype = C.c_size_t
+        # the same entry point with raw addresses, for walks over slices of one big array (walk_parallel)
+        L.orc_walk_ptr = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, _U64P, _U64P, _U64P,
+                                     C.c_uint64, C.c_void_p, C.c_size_t)(("orc_walk", L))
         L.orc_walk_direct.argtypes = walk_args
         L.orc_walk_direct.restype = C.c_size_t
         L.orc_create_herd.argtypes = [_U64P, _U64P, _U64P, C.c_size_t, C.c_int, _U64P, _U64P]
@@ -133,6 +136,34 @@ class Oracle:
         dps = np.zeros(dp_cap, dtype=DP_DTYPE)
         total = self.lib.orc_walk(x, y, d, n, nsteps, jd, jx, jy, dpmask, dps.ctypes.data, dp_cap)
         return dps[: min(total, dp_cap)], total
+
+    def walk_parallel(self, x, y, d, nsteps, jd, jx, jy, dpmask, threads=None, chunk=1 << 14):
+        """orc_walk over a thread pool: kangaroos are independent, so contiguous chunks walked separately give the
+        same states and the same distinguished points (ctypes releases the GIL; the C code keeps no global state in
+        the walk).  Updates x, y, d in place; returns every DP as one DP_DTYPE array with herd-wide kidx."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        n = x.shape[0]
+        assert x.shape == (n, 4) and y.shape == (n, 4) and d.shape == (n, 2)
+        assert x.flags.c_contiguous and y.flags.c_contiguous and d.flags.c_contiguous
+        threads = threads or min(os.cpu_count() or 1, 128)
+        addr = lambda a, i: C.c_void_p(a.ctypes.data + i * a.strides[0])  # noqa: E731
+        fn = self.lib.orc_walk_ptr
+
+        def one(c0):
+            m = min(chunk, n - c0)
+            # 4x the expected number of points, and room for a burst in a small chunk
+            cap = 64 + 4 * int(m * nsteps * (1.0 if dpmask == 0 else 2.0 ** -bin(dpmask).count("1")))
+            dps = np.zeros(cap, dtype=DP_DTYPE)
+            total = fn(addr(x, c0), addr(y, c0), addr(d, c0), m, nsteps, jd, jx, jy, dpmask, dps.ctypes.data, cap)
+            assert total <= cap, "DP buffer of a chunk overflowed"
+            dps = dps[:total]
+            dps["kidx"] += np.uint64(c0)
+            return dps
+
+        with ThreadPoolExecutor(threads) as ex:
+            parts = list(ex.map(one, range(0, n, chunk)))
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=DP_DTYPE)
 
     def walk_direct(self, x, y, d4, nsteps, jd, jx, jy, dpmask, dp_cap=1 << 20):
         """Host-view walk of Check.cpp (AddDirect, 256-bit distances mod n)."""

@@ -330,6 +330,86 @@ def test_full_size_herd_properties(kng, orc):
     assert np.array_equal(gx_[sub], ox) and np.array_equal(gy_[sub], oy) and np.array_equal(gd_[sub], od)
 
 
+@pytest.mark.parametrize("share", [1, 2, 3])
+@pytest.mark.parametrize("rp,dsplit", [(72, 1), (109, 0)])
+def test_every_walk_kernel_vs_oracle(kng, orc, share, rp, dsplit):
+    """All six instantiations of the walk kernel -- share 1/2/3 x {low-word distance streaming, both words} --
+    as the engine itself selects them: a 72-bit range streams only the low word, BASELINE configs[3]'s 109-bit range
+    (jump distances around 2^54) streams both.  States and the exact DP multiset over two launches."""
+    grid = (4, 4)
+    n = grid[0] * grid[1] * 128
+    x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=1000 + rp + share)
+    jd, jx, jy, _ = orc.jump_table(rp)
+    mask = orc.dp_mask(5)
+    eng = kng.GPUEngine(grid[0], grid[1], 0, 1 << 16, share=share, group=16)
+    eng.SetParams(mask, jd, jx, jy)
+    assert eng.get_option("dsplit") == dsplit and eng.get_option("share") == share
+    eng.SetWildOffset(wild_offset)
+    eng.SetKangaroos(x, y, ints_to_array(true_d))
+    ox, oy = x.copy(), y.copy()
+    od = ints_to_array(device_distances(true_d, wild_offset), 2)
+    key = lambda r: (int(r["kidx"]), tuple(int(v) for v in r["x"]), tuple(int(v) for v in r["d"]))  # noqa: E731
+    for _ in range(2):
+        eng.callKernel()
+        eng.wait()
+        got = eng.drain(raw=True)
+        want, _total = orc.walk(ox, oy, od, 64, jd, jx, jy, mask, dp_cap=1 << 20)
+        assert sorted(map(key, got)) == sorted(map(key, want))
+        gx, gy, gd = eng.GetKangaroos(raw=True)
+        assert np.array_equal(gx, ox) and np.array_equal(gy, oy) and np.array_equal(gd, od)
+    eng.close()
+
+
+@pytest.mark.parametrize("dsplit", [1, 0])
+def test_bench_config_total_parity(kng, orc, dsplit):
+    """BASELINE.md 3's gate taken literally, at the bench configuration (80-bit range, grid 512x128 = 2^23 kangaroos,
+    auto DP 14, default kernel): after one launch ALL 2^23 (x, y, d) triples and the COMPLETE distinguished-point
+    multiset equal the oracle's (walked over a thread pool: kangaroos are independent).  Both distance layouts."""
+    import kangaroo_amd.hostlib as hl
+
+    rp, gx, gy, dp = 80, 512, 128, 14
+    n = gx * gy * 128
+    _, kx, ky = hl.pubkey((1 << 79) + 0xC0FFEE123456789ABCD)
+    jd, jx, jy, _ = hl.jump_table(rp)
+    ojd, ojx, ojy, _ = orc.jump_table(rp)
+    assert np.array_equal(jd, ojd) and np.array_equal(jx, ojx) and np.array_equal(jy, ojy)
+    mask = hl.dp_mask(dp)
+    with kng.GPUEngine(gx, gy, 0, 1 << 17, dsplit=dsplit) as eng:
+        eng.SetParams(mask, jd, jx, jy)
+        assert eng.get_option("dsplit") == dsplit and eng.get_option("share") == 2 and eng.get_option("group") == 64
+        eng.CreateHerdOnDevice(rp, (kx, ky), seed=0xBEEF + dsplit)
+        x0, y0, d0 = eng.GetKangaroos(raw=True)
+        eng.callKernel()
+        eng.wait()
+        got = eng.drain(raw=True)
+        assert eng.lastLost == 0
+        x1, y1, d1 = eng.GetKangaroos(raw=True)
+    want = orc.walk_parallel(x0, y0, d0, 64, jd, jx, jy, mask)
+    assert np.array_equal(x1, x0) and np.array_equal(y1, y0) and np.array_equal(d1, d0)  # x0.. now hold the oracle's end state
+    assert len(got) == len(want) and 0.9 * (n * 64 >> dp) < len(got) < 1.1 * (n * 64 >> dp)
+
+    def canon(r):  # order by (kidx, d low word): a kangaroo may hit two distinguished points in one launch
+        o = np.lexsort((r["d"][:, 0], r["kidx"]))
+        return r["kidx"][o], r["x"][o], r["d"][o]
+
+    for a, b in zip(canon(got), canon(want)):
+        assert np.array_equal(a, b)
+
+
+def test_reference_gpu_check_harness_on_our_engine():
+    """The reference's own CPU/GPU parity harness, `kangaroo -gpu -check` (Check.cpp:467-621), unmodified, on our
+    engine: SetKangaroos, single SetKangaroo, Launch x2, GetKangaroos against SECPK1 AddDirect, every DP found.
+    -g 8,128 keeps the herd below Check's hard-coded maxFound (65536 DPs at dp=8, Check.cpp:418,492)."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "kangaroo_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/kangaroo_hip not built (needs /root/reference at build time)")
+    out = subprocess.run([exe, "-gpu", "-g", "8,128", "-check"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "CPU/GPU ok" in out.stdout, out.stdout[-2500:] + out.stderr[-500:]
+    assert "DP found" in out.stdout and "warning" not in out.stdout.lower()
+
+
 # ------------------------------------------------------------------ end to end: actually solve keys
 IN_TXT_RANGE_END = 0xFFFFFFFFFFFFFF          # the reference's shipped 56-bit known-answer input (in.txt)
 IN_TXT_PUBKEY = "02E9F43F810784FF1E91D8BC7C4FF06BFEE935DA71D7350734C3472FE305FEF82A"
