@@ -12,6 +12,11 @@ One "step" = one engine launch = NB_RUN = 64 jumps of every kangaroo (Kangaroo.c
 the previous launch's distinguished points drained to the host while the next one runs.
 Herds are independent per GPU (no collective on the data path; Kangaroo.cpp:1041-1047) -> weak scaling.
 
+N > 1 (torchrun or plain `--gpus N`): ONE process -- rank 0 -- drives all N devices through the host pipeline
+(kangaroo_amd/host/kng_solver: a thread per GPU, one shared distinguished-point table, as the reference's
+SolveKeyGPU threads share its HashTable); the other ranks only take part in the barriers.  The figure is then the
+wall-clock rate of the whole job including every DP insert, with the per-GPU kernel times beside it.
+
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on the engine's own
 stream; `cpu_baseline` (N=1 only) times the reference's SolveKeyCPU binary (oracle/_ref/kangaroo_cpu,
 built from the reference sources) on this host, or the oracle port when that binary is absent.
@@ -35,6 +40,9 @@ RANGE_START = int("B60E83280258A40F9CDF1649744D730D6E939DE92A2B" + "0" * 20, 16)
 KEY = RANGE_START + 0xC0FFEE123456789ABCD  # 80-bit offset, answer known
 ALG_BYTES_PER_JUMP = 160  # read + write of x(32) y(32) d(16): SURVEY.md 8d
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# BASELINE configs[3]: puzzle #110 (reference puzzle32.txt:6-9), interval [2^109, 2^110 - 1] -> rangePower 109, DP 25
+P110_START, P110_END = 0x2000000000000000000000000000, 0x3FFFFFFFFFFFFFFFFFFFFFFFFFFF
+P110_PUB = "0309976BA5570966BF889196B7FDF5A0F9A1E9AB340556EC29F8BB60599616167D"
 
 
 def log(msg):
@@ -112,6 +120,147 @@ def _kernel_name(eng) -> str:
     return f"kng_walk_share_kernel<{share}, {'true' if ds else 'false'}>"
 
 
+def _decompress(pub_hex):
+    P = 2**256 - 0x1000003D1
+    x = int(pub_hex[2:], 16)
+    y = pow((x * x * x + 7) % P, (P + 1) // 4, P)
+    return x, (y if (y & 1) == (int(pub_hex[:2], 16) & 1) else P - y)
+
+
+def _shifted_key(hl, key_xy, range_start):
+    """keyToSearch = K - start*G (Kangaroo.cpp:892-909)"""
+    if range_start == 0:
+        return key_xy
+    P = 2**256 - 0x1000003D1
+    _, sx, sy = hl.pubkey(range_start)
+    _, x, y = hl.point_add(key_xy, (sx, P - sy))
+    return x, y
+
+
+def _recorded_traffic(n, group, kernel):
+    """HBM bytes per launch from the last PMC pass (tools/gpu_round.sh keeps profiles/traffic.json current and fails
+    when it drifts); only quoted for the kernel and geometry it was measured on."""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(tfile) as f:
+            tj = json.load(f)
+        if tj.get("kangaroos") == n and tj.get("group") == group and tj.get("kernel") == kernel:
+            return tj.get("hbm_bytes_per_launch"), tj.get("source")
+    except Exception:
+        pass
+    return None, None
+
+
+def _timed_engine(k, hl, dev, gx, gy, range_power, key_xy, dp, steps, warmup, seed, **opts):
+    """W + K launches of one engine on a device-built herd; returns kernel name, mean kernel ms, geometry."""
+    import numpy as np
+
+    n = gx * gy * k.KNG_GRP_SIZE
+    jd, jx, jy, _ = hl.jump_table(range_power)
+    with k.GPUEngine(gx, gy, dev, max(65536 * 2, 2 * ((n * k.KNG_NB_RUN) >> dp)), **opts) as eng:
+        eng.SetParams(hl.dp_mask(dp), jd, jx, jy)
+        eng.CreateHerdOnDevice(range_power, key_xy, seed=seed)
+        ms = []
+        for i in range(warmup + steps):
+            eng.callKernel()
+            eng.wait()
+            eng.drain(raw=True)
+            if i >= warmup:
+                ms.append(eng.last_kernel_ms())
+        kms = float(np.mean(ms))
+        return {"kernel": _kernel_name(eng), "kernel_ms": round(kms, 3), "kangaroos": n, "group": eng.get_option("group"),
+                "lanes": eng.get_option("lanes"), "value": round(n * k.KNG_NB_RUN / (kms * 1e-3) / 1e6, 1), "unit": "MK/s",
+                "frac": round(n * k.KNG_NB_RUN * ALG_BYTES_PER_JUMP / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launches": steps}
+
+
+def secondary_lines(k, hl, dev, gx, gy) -> list:
+    """The other kernels and herds BASELINE.json names, next to (never instead of) the headline: kernel-rate only."""
+    out = []
+    try:  # configs[3]: 109-bit range, DP 25: jump distances ~2^54 -> both distance words stream (the non-dsplit kernel)
+        r = _timed_engine(k, hl, dev, gx, gy, 109, _shifted_key(hl, _decompress(P110_PUB), P110_START), 25, 10, 2, 0x110)
+        out.append(dict(r, name="configs[3] puzzle #110: 109-bit range, DP 25, default grid", bytes_per_jump_design=224))
+    except Exception as e:
+        out.append({"name": "configs[3]", "error": str(e)})
+    try:  # configs[2] read literally: herd = 2*CU x 128 kangaroos = grid 2*CU x 1
+        _, kx, ky = hl.pubkey(KEY)
+        r = _timed_engine(k, hl, dev, gx, 1, RANGE_POWER, _shifted_key(hl, (kx, ky), RANGE_START), hl.suggest_dp(RANGE_POWER, gx * 128), 10, 2, 0x65536)
+        out.append(dict(r, name="configs[2] literal herd: 2*CU x 128 = %d kangaroos, 80-bit range" % (gx * 128)))
+    except Exception as e:
+        out.append({"name": "configs[2] literal herd", "error": str(e)})
+    return out
+
+
+def bench_multi(args, ranks, n_gpus):
+    """N > 1: rank 0 runs the whole job in one process (a host thread per GPU, ONE distinguished-point table)."""
+    import numpy as np
+
+    from kangaroo_amd.dist import timed_on_rank0
+
+    out = None
+    job = {}
+    if ranks.rank == 0:
+        import kangaroo_amd as k
+        import kangaroo_amd.hostlib as hl
+        from kangaroo_amd import solver as sv
+
+        k.load_library()
+        if k.device_count() < n_gpus:
+            raise SystemExit(f"--gpus {n_gpus} but only {k.device_count()} HIP devices are visible")
+        info = k.device_info(0)
+        if args.grid:
+            gx, gy = (int(v) for v in args.grid.split(","))
+        else:
+            gx, gy = k.default_grid(0)
+        n = gx * gy * k.KNG_GRP_SIZE
+        dp = hl.suggest_dp(RANGE_POWER, n * n_gpus)  # totalRW of Kangaroo.cpp:946-993
+        _, kx, ky = hl.pubkey(KEY)
+        s = sv.Solver(RANGE_START, RANGE_START + (1 << RANGE_POWER) - 1, (kx, ky), gpus=tuple(range(n_gpus)), grid=(gx, gy), dp=dp,
+                      seed=0xBEEF, max_launches=args.steps, warmup_launches=args.warmup)
+        t0 = time.time()
+        s.prepare()  # engines, herds (built on the GPUs), W discarded launches per GPU
+        log(f"{n_gpus} x {info['name']}: 2^{np.log2(n):.0f} kangaroos each, dp {dp}; prepared in {time.time() - t0:.1f} s")
+        job["run"] = lambda: (s.start(), s.wait(600))
+    elapsed = timed_on_rank0(ranks, job.get("run"))
+    if ranks.rank == 0:
+        st = s.stats()
+        per_gpu = []
+        for g in range(n_gpus):
+            gs = s.gpu_stats(g)
+            kms = gs["kernel_ms_sum"] / max(1, gs["launches"])
+            per_gpu.append({"gpu": g, "launches": gs["launches"], "kernel_ms": round(kms, 3),
+                            "kernel_rate": round(gs["kangaroos"] * k.KNG_NB_RUN / (kms * 1e-3) / 1e6, 1)})
+        load = s.consumer_load()
+        s.stop()
+        s.close()
+        assert all(p["launches"] == args.steps for p in per_gpu), per_gpu
+        jumps = n_gpus * n * k.KNG_NB_RUN * args.steps
+        kms = float(np.mean([p["kernel_ms"] for p in per_gpu]))
+        achieved = n * k.KNG_NB_RUN * ALG_BYTES_PER_JUMP / (kms * 1e-3) / 1e9
+        kernel = "kng_walk_share_kernel<2, true>"
+        traffic, tsrc = _recorded_traffic(n, 64, kernel)
+        out = {
+            "metric": "kangaroo jumps/sec (MK/s)", "value": round(jumps / elapsed / 1e6, 2), "unit": "MK/s", "n_gpus": n_gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {
+                "workload": f"80-bit range single key, auto DP {dp} (population of {n_gpus} GPUs), herd {gx}x{gy}x128 = 2^{np.log2(n):.0f} "
+                            f"kangaroos/GPU, {k.KNG_NB_RUN} jumps/launch",
+                "range_power": RANGE_POWER, "dp": dp, "grid": [gx, gy], "kangaroos_per_gpu": n, "device": info["name"], "arch": info["arch"],
+                "parallelism": f"independent herds x{n_gpus}: one process, a host thread per GPU, ONE shared host DP table, no collective",
+                "dps_per_step": round(st["dps"] / args.steps, 1), "dps_lost": st["dps_lost"], "table_consumers": len(load),
+                "what_is_timed": "kngs_start .. every GPU finished its K launches AND every distinguished point is in the table",
+            },
+            "per_gpu": per_gpu,
+            "kernel_rate_sum": round(sum(p["kernel_rate"] for p in per_gpu), 1),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "traffic_source": tsrc, "kernel": kernel, "kernel_ms": round(kms, 3),
+                         "alg_bytes_per_launch": n * k.KNG_NB_RUN * ALG_BYTES_PER_JUMP, "note": "per GPU, mean over GPUs"},
+        }
+    ranks.close()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +271,7 @@ def main():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the end-to-end host-pipeline sample (N=1 only)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary kernel-rate lines (N=1 only)")
     ap.add_argument("--host-herd", action="store_true", help="build the herd on the host and upload it (default: on the GPU)")
     args = ap.parse_args()
 
@@ -134,7 +284,9 @@ def main():
     rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
     if world != args.gpus and world > 1:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
-    n_gpus = world
+    n_gpus = world if world > 1 else max(1, args.gpus)
+    if n_gpus > 1:
+        return bench_multi(args, ranks, n_gpus)
 
     import numpy as np
 
@@ -221,16 +373,7 @@ def main():
     value = whole_job_rate(ranks, jumps_per_step, args.steps, elapsed) / 1e6  # MK/s, whole job
     kms = float(np.mean(kernel_ms))
     achieved = jumps_per_step * ALG_BYTES_PER_JUMP / (kms * 1e-3) / 1e9  # GB/s, per GPU
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-measured HBM bytes per launch, if recorded
-    if os.path.exists(tfile):
-        try:
-            with open(tfile) as f:
-                tj = json.load(f)
-            if tj.get("kangaroos") == n and tj.get("group") == eng.get_option("group"):
-                traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic, traffic_source = _recorded_traffic(n, eng.get_option("group"), _kernel_name(eng))
     out = {
         "metric": "kangaroo jumps/sec (MK/s)",
         "value": round(value, 2),
@@ -254,13 +397,15 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "kernel": _kernel_name(eng),
             "kernel_ms": round(kms, 3),
             "alg_bytes_per_launch": jumps_per_step * ALG_BYTES_PER_JUMP,
         },
     }
     eng.close()
+    if rank == 0 and n_gpus == 1 and not args.no_secondary:
+        out["secondary"] = secondary_lines(k, hl, dev, gx, gy)
     if rank == 0 and n_gpus == 1 and not args.no_pipeline:
         # reported next to the hot-path figure, never instead of it: the same workload through the host
         # pipeline (kangaroo_amd/host/kng_solver.cpp): every DP converted, queued and inserted into the table

@@ -1,8 +1,10 @@
-"""Multi-GPU plumbing: one process per GPU, independent herds, NO collective on the data path.
+"""Multi-GPU plumbing: independent herds, NO collective on the data path.
 
-The jump path shards embarrassingly (disjoint herds per GPU, Kangaroo.cpp:1041-1047);
-the only cross-rank communication is the rendezvous, the barrier around the timed region and the
-max-reduce of the elapsed time.  backend "nccl" (= RCCL on ROCm) on GPUs, "gloo" in the CPU tests.
+The jump path shards embarrassingly (disjoint herds per GPU, Kangaroo.cpp:1041-1047); what the GPUs
+share is the HOST distinguished-point table.  Launched as one process per GPU (torchrun), rank 0 therefore drives
+every device through kng_solver (a host thread per GPU, one table) and the other ranks only take part in the
+rendezvous, the barriers around the timed region and the max-reduce of the elapsed time (timed_on_rank0).
+backend "nccl" (= RCCL on ROCm) on GPUs, "gloo" in the CPU tests.
 """
 from __future__ import annotations
 
@@ -83,6 +85,17 @@ def timed_steps(ranks: Ranks, step: Callable[[int], None], finish: Callable[[], 
     for i in range(steps):
         step(i)
     finish()
+    ranks.sync()
+    return ranks.max_over_ranks(time.perf_counter() - t0)
+
+
+def timed_on_rank0(ranks: Ranks, job: Callable[[], object] | None) -> float:
+    """Time job() on rank 0 between two barrier+sync pairs; every rank returns the same elapsed seconds (max over
+    ranks: the idle ranks measure the same interval through the barriers)."""
+    ranks.sync()
+    t0 = time.perf_counter()
+    if ranks.rank == 0 and job is not None:
+        job()
     ranks.sync()
     return ranks.max_over_ranks(time.perf_counter() - t0)
 

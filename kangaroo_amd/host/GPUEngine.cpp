@@ -8,8 +8,9 @@
 //                             reference's link line and the unmodified program runs on the MI355X.
 //                             The reference header's private fields are CUDA-era buffers we do not
 //                             need; the engine handle is parked in `inputKangaroo`.
-// Errors are loud: the reference printf()s and carries on with an unusable object
-// (GPUEngine.cu:144-253, callers never check `initialised`); we print and exit(1).
+// Errors: like the reference (GPUEngine.cu:144-253) a failure is reported on stderr and leaves the object unusable
+// -- `initialised` cleared, every later call refused with a message, callKernel / callKernelAndWait / Launch return
+// false -- but nothing in here ends the process: that decision belongs to the program that owns the object.
 #ifdef KNG_REFERENCE_HEADER
 #include "GPU/GPUEngine.h"
 #include "kangaroo_hip.h"
@@ -27,11 +28,15 @@
 
 static const size_t INT_STRIDE = sizeof(Int) / sizeof(uint64_t);
 
-static void die(const char *where) {
-  fprintf(stderr, "GPUEngine: %s: %s\n", where, kng_last_error());
-  exit(1);
+// report a failed C-ABI call and put the object out of service; evaluates to true on success
+static bool in_service(bool initialised, const void *engine, const char *where) {
+  if (initialised && engine) return true;
+  fprintf(stderr, "GPUEngine: %s refused: the engine is out of service after an earlier error\n", where);
+  return false;
 }
-#define KNG_MUST(call, where) do { if ((call) != KNG_OK) die(where); } while (0)
+#define usable(where) in_service(initialised, ENGINE, where)
+#define KNG_MUST(call, where) \
+  (!usable(where) ? false : ((call) == KNG_OK ? true : (fprintf(stderr, "GPUEngine: %s: %s\n", where, kng_last_error()), initialised = false, false)))
 
 GPUEngine::GPUEngine(int nbThreadGroup, int nbThreadPerGroup, int gpuId, uint32_t maxFound) {
 #ifdef KNG_REFERENCE_HEADER
@@ -40,9 +45,9 @@ GPUEngine::GPUEngine(int nbThreadGroup, int nbThreadPerGroup, int gpuId, uint32_
   outputItem = NULL;
   outputItemPinned = NULL;
   jumpPinned = NULL;
-  initialised = false;
   dpMask = 0;
 #endif
+  initialised = false;
   this->nbThreadPerGroup = nbThreadPerGroup;
   this->nbThread = nbThreadGroup * nbThreadPerGroup;
   this->maxFound = maxFound;
@@ -50,12 +55,19 @@ GPUEngine::GPUEngine(int nbThreadGroup, int nbThreadPerGroup, int gpuId, uint32_
   wildOffset.SetInt32(0);
   ENGINE = NULL;
   ITEMBUF = NULL;
+  deviceName = "GPU #" + std::to_string(gpuId) + " (unusable)";
   kng_engine *h = NULL;
-  KNG_MUST(kng_create(gpuId, nbThreadGroup, nbThreadPerGroup, maxFound, &h), "kng_create");
+  if (kng_create(gpuId, nbThreadGroup, nbThreadPerGroup, maxFound, &h) != KNG_OK) {
+    fprintf(stderr, "GPUEngine: kng_create: %s\n", kng_last_error());
+    return;
+  }
   ENGINE = h;
   // host landing buffer for one launch's DPs, allocated once (pinned)
   ITEMBUF = (kng_item *)kng_alloc_pinned((size_t)maxFound * sizeof(kng_item));
-  if (!ITEMBUF) die("kng_alloc_pinned");
+  if (!ITEMBUF) {
+    fprintf(stderr, "GPUEngine: kng_alloc_pinned: %s\n", kng_last_error());
+    return;
+  }
   char name[256] = "", arch[64] = "";
   int cu = 0;
   kng_device_info(gpuId, name, sizeof name, &cu, NULL, arch, sizeof arch);
@@ -63,9 +75,7 @@ GPUEngine::GPUEngine(int nbThreadGroup, int nbThreadPerGroup, int gpuId, uint32_
   // GPUEngine.cu:176-182 banner; the CUDA "cores per SM" table has no AMD entry (it would print 0)
   snprintf(tmp, sizeof tmp, "GPU #%d %s (%dx%d cores) Grid(%dx%d)", gpuId, name, cu, 64, nbThreadGroup, nbThreadPerGroup);
   deviceName = std::string(tmp);
-#ifdef KNG_REFERENCE_HEADER
   initialised = true;
-#endif
 }
 
 GPUEngine::~GPUEngine() {
@@ -81,6 +91,7 @@ int GPUEngine::GetNbThread() { return nbThread; }
 int GPUEngine::GetGroupSize() { return KNG_GRP_SIZE; }
 
 int GPUEngine::GetMemory() {
+  if (!ENGINE) return 0;
   // the reference returns int and overflows above 2 GiB (GPUEngine.h:79): saturate
   uint64_t b = kng_memory_bytes(ENGINE);
   return b > 0x7FFFFFFFULL ? 0x7FFFFFFF : (int)b;
@@ -126,10 +137,11 @@ void GPUEngine::SetParams(uint64_t dpMask, Int *distance, Int *px, Int *py) {
     memcpy(jx[i], px[i].bits64, 32);
     memcpy(jy[i], py[i].bits64, 32);
   }
-  KNG_MUST(kng_set_params(ENGINE, dpMask, &jd[0][0], &jx[0][0], &jy[0][0]), "SetParams");
+  (void)KNG_MUST(kng_set_params(ENGINE, dpMask, &jd[0][0], &jx[0][0], &jy[0][0]), "SetParams");
 }
 
 void GPUEngine::SetKangaroos(Int *px, Int *py, Int *d) {
+  if (!usable("SetKangaroos")) return;
   const uint64_t n = kng_nb_kangaroos(ENGINE);
   // device distances: wild (odd index) += wildOffset mod n (GPUEngine.cu:406-411)
   std::vector<uint64_t> dd(2 * n);
@@ -140,13 +152,14 @@ void GPUEngine::SetKangaroos(Int *px, Int *py, Int *d) {
     dd[2 * i] = dOff.bits64[0];
     dd[2 * i + 1] = dOff.bits64[1];
   }
-  KNG_MUST(kng_set_kangaroos(ENGINE, px[0].bits64, INT_STRIDE, py[0].bits64, INT_STRIDE, dd.data(), 2, n), "SetKangaroos");
+  (void)KNG_MUST(kng_set_kangaroos(ENGINE, px[0].bits64, INT_STRIDE, py[0].bits64, INT_STRIDE, dd.data(), 2, n), "SetKangaroos");
 }
 
 void GPUEngine::GetKangaroos(Int *px, Int *py, Int *d) {
+  if (!usable("GetKangaroos")) return;
   const uint64_t n = kng_nb_kangaroos(ENGINE);
   std::vector<uint64_t> dd(2 * n);
-  KNG_MUST(kng_get_kangaroos(ENGINE, px[0].bits64, INT_STRIDE, py[0].bits64, INT_STRIDE, dd.data(), 2, n), "GetKangaroos");
+  if (!KNG_MUST(kng_get_kangaroos(ENGINE, px[0].bits64, INT_STRIDE, py[0].bits64, INT_STRIDE, dd.data(), 2, n), "GetKangaroos")) return;
   for (uint64_t i = 0; i < n; i++) {
     px[i].bits64[4] = 0;
     py[i].bits64[4] = 0;
@@ -163,10 +176,11 @@ void GPUEngine::SetKangaroo(uint64_t kIdx, Int *px, Int *py, Int *d) {
   Int dOff;
   dOff.Set(d);
   if (kIdx % 2 == WILD) dOff.ModAddK1order(&wildOffset); // GPUEngine.cu:526
-  KNG_MUST(kng_set_kangaroo(ENGINE, kIdx, px->bits64, py->bits64, dOff.bits64), "SetKangaroo");
+  (void)KNG_MUST(kng_set_kangaroo(ENGINE, kIdx, px->bits64, py->bits64, dOff.bits64), "SetKangaroo");
 }
 
 bool GPUEngine::callKernel() {
+  if (!usable("callKernel")) return false;
   if (kng_launch(ENGINE) != KNG_OK) {
     printf("GPUEngine: Kernel: %s\n", kng_last_error());
     return false;
@@ -185,6 +199,7 @@ bool GPUEngine::callKernelAndWait() {
 
 bool GPUEngine::Launch(std::vector<ITEM> &hashFound, bool spinWait) {
   hashFound.clear();
+  if (!usable("Launch")) return false;
   // results of the PREVIOUS kernel (GPUEngine.cu:607-676).  Nothing is outstanding on the very
   // first call of Check.cpp:526; the reference then reads an uninitialised counter.
   const bool had = kng_outstanding(ENGINE) == 1;

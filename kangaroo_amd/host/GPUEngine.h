@@ -62,6 +62,7 @@ public:
   static void FreePinnedMemory(void *buff);
 
 private:
+  bool initialised;   // as in the reference (GPUEngine.h:67): cleared by a failed constructor or call
   kng_engine *engine; // the whole device side lives behind the C ABI
   kng_item *itemBuf;  // pinned landing buffer for one launch's DPs
   Int wildOffset;

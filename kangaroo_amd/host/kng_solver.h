@@ -44,6 +44,8 @@ typedef struct kngs_config {
                                for tests and benchmarks: equal seeds rebuild equal herds, whose walks retrace trails
                                already in a restored table */
     uint64_t max_launches;  /* per GPU, 0 = until solved or stopped */
+    uint32_t warmup_launches; /* benchmarks: launches run and discarded by kngs_prepare, outside any timing */
+    uint32_t reserved;
 } kngs_config;
 
 typedef struct kngs_stats {
@@ -71,7 +73,10 @@ void kngs_destroy(kngs_solver *s);
 /* restore hash table, counters and (when the file has them) herds from a HEADW work file written by this
  * library or by the reference; range and key must match the configuration.  Call before kngs_start. */
 int kngs_load(kngs_solver *s, const char *path);
-/* create the engines, build or upload the herds, start the GPU and consumer threads */
+/* create the engines and build or upload the herds (everything that is not the search itself); optional --
+ * kngs_start does it when it has not been done.  A benchmark calls it first so that its clock only sees the search. */
+int kngs_prepare(kngs_solver *s);
+/* (kngs_prepare, then) start the GPU and consumer threads */
 int kngs_start(kngs_solver *s);
 /* block until solved (returns 1), every GPU has done max_launches (2), or `seconds` elapsed (0); <0 error */
 int kngs_wait(kngs_solver *s, double seconds);

@@ -37,7 +37,7 @@ class _Config(C.Structure):
     _fields_ = [("range_start", C.c_uint64 * 4), ("range_end", C.c_uint64 * 4), ("key_x", C.c_uint64 * 4),
                 ("key_y", C.c_uint64 * 4), ("dp", C.c_int32), ("n_gpus", C.c_int32), ("gpu_ids", C.c_int32 * MAX_GPUS),
                 ("grid_x", C.c_int32), ("grid_y", C.c_int32), ("max_found", C.c_uint32), ("consumers", C.c_int32),
-                ("seed", C.c_uint64), ("max_launches", C.c_uint64)]
+                ("seed", C.c_uint64), ("max_launches", C.c_uint64), ("warmup_launches", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class _Stats(C.Structure):
@@ -85,6 +85,7 @@ def _lib() -> C.CDLL:
         L.kngs_destroy.restype = None
         L.kngs_load.argtypes = [C.c_void_p, C.c_char_p]
         L.kngs_start.argtypes = [C.c_void_p]
+        L.kngs_prepare.argtypes = [C.c_void_p]
         L.kngs_wait.argtypes = [C.c_void_p, C.c_double]
         L.kngs_stop.argtypes = [C.c_void_p]
         L.kngs_result.argtypes = [C.c_void_p, _U64P]
@@ -212,12 +213,12 @@ class Solver:
     """Kangaroo::SolveKeyGPU for N GPUs (Kangaroo.cpp:510-644, :1019-1063) over the C-ABI engine."""
 
     def __init__(self, range_start: int, range_end: int, key, *, gpus=(0,), grid=(0, 0), dp: int = -1, max_found: int = 0,
-                 consumers: int = 0, seed: int = 0, max_launches: int = 0):
+                 consumers: int = 0, seed: int = 0, max_launches: int = 0, warmup_launches: int = 0):
         """seed 0 (default) draws a herd seed like the reference does from the clock (main.cpp:177); stats()["seed"]
         reports it.  Pass a fixed seed only for tests and benchmarks: equal seeds rebuild equal herds."""
         self._L = _lib()
         cfg = _Config(dp=dp, n_gpus=len(gpus), grid_x=grid[0], grid_y=grid[1], max_found=max_found, consumers=consumers,
-                      seed=seed & ((1 << 64) - 1), max_launches=max_launches)
+                      seed=seed & ((1 << 64) - 1), max_launches=max_launches, warmup_launches=warmup_launches)
         for name, v in (("range_start", range_start), ("range_end", range_end), ("key_x", key[0]), ("key_y", key[1])):
             for i in range(4):
                 getattr(cfg, name)[i] = (v >> (64 * i)) & ((1 << 64) - 1)
@@ -245,6 +246,10 @@ class Solver:
 
     def load(self, path: str):
         self._check(self._L.kngs_load(self._h, path.encode()))
+
+    def prepare(self):
+        """engines, herds and the warm-up launches; start() does it when it has not been done"""
+        self._check(self._L.kngs_prepare(self._h))
 
     def start(self):
         self._check(self._L.kngs_start(self._h))

@@ -81,6 +81,30 @@ int main() {
     if (memcmp(qx, it.x.bits64, 32)) bad++;
   }
   if (bad) { printf("CPP GPUEngine NOT ok: %llu faults\n", (unsigned long long)bad); return 1; }
-  printf("GPU: %s\nCPP GPUEngine ok\n", eng.deviceName.c_str());
+  printf("GPU: %s\n", eng.deviceName.c_str());
+
+  // error behaviour at the boundary (GPUEngine.cu:144-253, :540-557): a constructor that cannot allocate its herd
+  // (2^33 kangaroos = 960 GB of state) reports it and leaves an object whose calls are refused -- callKernel / Launch
+  // return false -- and the process lives on.
+  {
+    GPUEngine big(1 << 16, 1024, 0, 65536);
+    std::vector<ITEM> none;
+    if (big.callKernel() || big.callKernelAndWait() || big.Launch(none) || !none.empty() || big.GetMemory() != 0) {
+      printf("an unusable engine must refuse to launch\n");
+      return 1;
+    }
+    big.SetParams(kngh_dp_mask(dp), jdist, jpx, jpy); // refused with a message, no crash
+    big.SetKangaroo(0, &px[0], &py[0], &pd[0]);
+  }
+  {
+    GPUEngine nodev(2, 64, 9999, 65536); // no such device
+    if (nodev.callKernel()) { printf("an engine without a device must refuse to launch\n"); return 1; }
+  }
+  // calls out of sequence on a healthy engine are refused one by one and do not put it out of service
+  {
+    GPUEngine fresh(2, 64, 0, 4096);
+    if (fresh.callKernel()) { printf("launch without parameters must fail\n"); return 1; }
+  }
+  printf("CPP GPUEngine ok\n");
   return 0;
 }

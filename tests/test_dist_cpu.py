@@ -22,6 +22,11 @@ WORKER = textwrap.dedent("""
     n = 512 * 128 * 128
     out = {"rank": r.rank, "device": r.device, "world": r.world, "seed": r.herd_seed(0xBEEF), "elapsed": elapsed,
            "rate": whole_job_rate(r, n * 64, 5, elapsed), "dp": hl.suggest_dp(80, r.total_kangaroos(n))}
+    # N > 1 bench protocol: rank 0 runs the whole job (all GPUs, one host table), the others bracket it with barriers
+    from kangaroo_amd.dist import timed_on_rank0
+    ran = []
+    out["job_elapsed"] = timed_on_rank0(r, (lambda: (time.sleep(0.15), ran.append(1))) if r.rank == 0 else None)
+    out["ran"] = len(ran)
     print("RESULT " + json.dumps(out), flush=True)
     r.close()
 """) % ROOT
@@ -63,6 +68,9 @@ def test_two_ranks_gloo(tmp_path):
     assert abs(res[0]["rate"] - 2 * n * 64 * 5 / res[0]["elapsed"]) < 1e-3
     # auto DP from the TOTAL kangaroo count (Kangaroo.cpp:980-988): 2 x 2^23 on 80 bits -> 13
     assert res[0]["dp"] == res[1]["dp"] == 13
+    # the single-process job of rank 0 is seen with the same duration by every rank
+    assert [r["ran"] for r in res] == [1, 0]
+    assert abs(res[0]["job_elapsed"] - res[1]["job_elapsed"]) < 1e-9 and 0.15 <= res[0]["job_elapsed"] < 1.0
 
 
 def test_single_rank_needs_no_torch_distributed():

@@ -396,6 +396,17 @@ def test_bench_config_total_parity(kng, orc, dsplit):
         assert np.array_equal(a, b)
 
 
+def test_allocation_failure_is_reported_not_fatal(kng):
+    """KNG_E_ALLOC: a herd that cannot fit the device (2^33 kangaroos, 960 GB of state) fails kng_create with the
+    allocation error code and leaks nothing -- a normal engine can be created right after."""
+    with pytest.raises(kng.EngineError, match=r"error -2: herd state"):
+        kng.GPUEngine(1 << 16, 1024, 0, 65536)
+    with pytest.raises(kng.EngineError, match=r"error -2: (dp items|pinned dp items)"):
+        kng.GPUEngine(2, 2, 0, 0xFFFFFFFF)  # 2^32 DP slots x 64 B x 2 buffers
+    with kng.GPUEngine(2, 2, 0, 1024) as eng:
+        assert eng.nbKangaroo == 512
+
+
 def test_reference_gpu_check_harness_on_our_engine():
     """The reference's own CPU/GPU parity harness, `kangaroo -gpu -check` (Check.cpp:467-621), unmodified, on our
     engine: SetKangaroos, single SetKangaroo, Launch x2, GetKangaroos against SECPK1 AddDirect, every DP found.

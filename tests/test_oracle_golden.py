@@ -4,6 +4,8 @@ tests/golden/ref_vectors.json is written by oracle/refprobe.cpp, which links the
 reference SECPK1 + Kangaroo objects (tools/make_golden.py).  An independent pure-Python
 restatement (pow(x,-1,p), textbook affine addition) cross-checks both.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -172,3 +174,65 @@ def test_dp_mask(orc):
     assert orc.dp_mask(14) == 0xFFFC000000000000
     assert orc.dp_mask(64) == 0xFFFFFFFFFFFFFFFF
     assert orc.dp_mask(70) == 0xFFFFFFFFFFFFFFFF
+
+
+# ---------------------------------------------------------------- BASELINE configs[0]: 32-bit CPU plumbing
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG0_START, CFG0_END = 0x80000000, 0xFFFFFFFF
+CFG0_PUB = "0209C58240E50E3BA3F833C82655E8725C037A2294E14CF5D73A5DF8D56159DE69"
+CFG0_PRIV = 0xB862A62E  # SURVEY 8(d) config 1 (puzzle32.txt itself holds no 32-bit key)
+
+
+def test_config0_reference_cpu_program_solves_the_32bit_key(tmp_path):
+    """The unmodified reference, CPU target, `-t 1` (SolveKeyCPU, Kangaroo.cpp:334-506) on BASELINE configs[0]."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "kangaroo_cpu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/kangaroo_cpu not built (needs /root/reference at build time)")
+    cfg = tmp_path / "in32.txt"
+    cfg.write_text("%X\n%X\n%s\n" % (CFG0_START, CFG0_END, CFG0_PUB))
+    out = subprocess.run([exe, "-t", "1", str(cfg)], capture_output=True, text=True, timeout=120)
+    assert "Priv: 0x%X" % CFG0_PRIV in out.stdout, out.stdout[-1500:]
+
+
+def test_config0_oracle_walk_finds_the_same_key(orc):
+    """The same input through the oracle alone -- herd (CreateHerd), jump table, batched walk (orc_walk), a Python dict
+    as the DP table, CollisionCheck's four sign cases -- i.e. the whole SolveKeyCPU data flow restated: same answer."""
+    from helpers import ints_to_array
+
+    rp = 31
+    x = int(CFG0_PUB[2:], 16)
+    y = pow((x * x * x + 7) % P, (P + 1) // 4, P)
+    if (y & 1) != (int(CFG0_PUB[:2], 16) & 1):
+        y = P - y
+    # keyToSearch = K - start*G (Kangaroo.cpp:892-909)
+    _, sx, sy = orc.pubkey(CFG0_START)
+    kx, ky = (np.zeros(4, np.uint64) for _ in range(2))
+    orc.lib.orc_add_direct(kx, ky, ints_to_array([x])[0], ints_to_array([y])[0], ints_to_array([sx])[0], ints_to_array([P - sy])[0])
+    ksx, ksy = array_to_ints([kx])[0], array_to_ints([ky])[0]
+    n, woff = 256, ((1 << rp) - 1) >> 1
+    rng = np.random.default_rng(32)
+    true_d = [int(rng.integers(0, 1 << rp)) if i % 2 == 0 else (int(rng.integers(0, 1 << rp)) - woff) % N_ORDER for i in range(n)]
+    hx, hy = orc.create_herd(ints_to_array(true_d), 0, ksx, ksy)
+    dev = ints_to_array([(d + woff) % N_ORDER if i & 1 else d for i, d in enumerate(true_d)], 2)
+    jd, jx, jy, _ = orc.jump_table(rp)
+    table, found = {}, None
+    for _ in range(400):
+        dps, _total = orc.walk(hx, hy, dev, 16, jd, jx, jy, orc.dp_mask(3))
+        for r in dps:
+            k = int(r["kidx"])
+            d = array_to_ints([r["d"]])[0]
+            d = (d - woff) % N_ORDER if k & 1 else d
+            key = tuple(int(v) for v in r["x"])
+            other = table.get(key)
+            if other is None:
+                table[key] = (k & 1, d)
+            elif other[0] != (k & 1):
+                td, wd = (d, other[1]) if k & 1 == 0 else (other[1], d)
+                for cand in ((td - wd) % N_ORDER, (td + wd) % N_ORDER, (-td - wd) % N_ORDER, (wd - td) % N_ORDER):
+                    if orc.pubkey(cand)[1:] == (ksx, ksy):
+                        found = cand + CFG0_START
+        if found is not None:
+            break
+    assert found == CFG0_PRIV

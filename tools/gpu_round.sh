@@ -15,16 +15,39 @@ if [ -x oracle/_ref/kangaroo_hip ]; then
   tail -12 $OUT/${TAG}_ref_gpu_check.txt
 fi
 echo "== bench"; python bench.py 2> $OUT/${TAG}_bench.err | tee $OUT/${TAG}_bench.json; tail -3 $OUT/${TAG}_bench.err
+echo "== bench --gpus 2 on this one device is not possible; host path at the 8-GPU DP rate instead"
+[ -x tools/dp_ingest_bench ] && ./tools/dp_ingest_bench --feeders 8 --launches 40 --launch-ms 25 | tee $OUT/${TAG}_dp_ingest.txt
 echo "== rocprofv3 kernel trace"
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o kt -- python $OLDPWD/bench.py --no-cpu-baseline --no-pipeline > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o kt -- python $OLDPWD/bench.py --no-cpu-baseline --no-pipeline --no-secondary > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err)
 find $OUT/${TAG}_prof -name "*kernel_stats*" | head -3
 for f in $(find $OUT/${TAG}_prof -name "*kernel_stats.csv"); do cp $f $OUT/${TAG}_kernel_stats.csv; done
 cat $OUT/${TAG}_kernel_stats.csv 2>/dev/null | head -8
 echo "== rocprofv3 PMC passes (counters only)"
 for C in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && rocprofv3 --pmc $C --output-format csv -d $OUT/${TAG}_pmc_$C -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline > /dev/null 2> $OUT/${TAG}_pmc_$C.err)
+  (cd /tmp && rocprofv3 --pmc $C --output-format csv -d $OUT/${TAG}_pmc_$C -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-secondary > /dev/null 2> $OUT/${TAG}_pmc_$C.err)
   f=$(find $OUT/${TAG}_pmc_$C -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py $f $C | tee $OUT/${TAG}_pmc_$C.txt
 done
-ls -R $OUT/${TAG}_prof | head -20
 rm -rf $OUT/${TAG}_prof $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE
+# HBM bytes per launch of the bench's walk kernel from the two passes (FETCH doubled: gfx950 note in MI355X_MICROARCH.md),
+# against the figure bench.py quotes from profiles/traffic.json: more than 2 % apart = the recorded figure is stale
+python - $OUT/${TAG}_pmc_FETCH_SIZE.txt $OUT/${TAG}_pmc_WRITE_SIZE.txt $OUT/${TAG}_traffic.json <<'PY'
+import json, re, sys
+def mean(path, kernel):
+    for line in open(path):
+        if kernel in line:
+            return float(re.search(r"mean=([0-9.e+]+)", line).group(1))
+    raise SystemExit(f"{kernel} not in {path}")
+rec = json.load(open("profiles/traffic.json"))
+k = rec["kernel"]
+bytes_per_launch = (2 * mean(sys.argv[1], k) + mean(sys.argv[2], k)) * 1024
+new = dict(rec, hbm_bytes_per_launch=int(round(bytes_per_launch, -7)), source=f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled per the gfx950 note ({sys.argv[3].split('/')[-1]})")
+json.dump(new, open(sys.argv[3], "w"), indent=1)
+drift = bytes_per_launch / rec["hbm_bytes_per_launch"] - 1
+print(f"walk kernel {k}: {bytes_per_launch / 1e9:.2f} GB per launch = {bytes_per_launch / (rec['kangaroos'] * 64):.1f} B/jump; profiles/traffic.json says "
+      f"{rec['hbm_bytes_per_launch'] / 1e9:.2f} GB ({drift * 100:+.2f} %)")
+if abs(drift) > 0.02:
+    print("TRAFFIC DRIFT: update profiles/traffic.json from", sys.argv[3])
+    sys.exit(3)
+PY
+echo "traffic check rc=$?"
