@@ -637,6 +637,7 @@ int kng_create(int dev, int grid_x, int grid_y, uint32_t max_found, kng_engine *
 
     auto bail = [&](int code) {
         kng_destroy(h);
+        (void)hipGetLastError(); // a failed hipMalloc leaves a sticky error that the next kernel launch would report as its own
         return code;
     };
     hipError_t e;

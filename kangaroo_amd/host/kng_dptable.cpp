@@ -7,9 +7,20 @@
 // key, so the fine arrays, read in index order, ARE the sorted bucket -- and k grows by 2 whenever the bucket holds
 // more than 32 entries per fine array (a local re-split by the one thread that owns the bucket).  An insertion then
 // moves ~0.3 KB whatever the size of the table; the serialised form is unchanged.
+//
+// Memory.  Dozens of consumer threads growing small arrays through malloc, in one address space that gains gigabytes
+// per second, serialise on the kernel's mmap lock (heap growth + page faults): measured on the 256-thread GPU host,
+// 16 consumers inserted 30 M points/s and 96 consumers 11 M (profiles/r02_dp_ingest_*.txt).  The table therefore owns
+// its memory: every bucket belongs to one of 64 arenas (by a scramble of its index, the same one the solver uses to
+// assign buckets to consumers, so an arena is shared by at most two threads; a spin lock covers that), an arena
+// takes regions of 64 KiB doubling to 2 MiB from the OS (huge pages where the system grants them), carves blocks of 64, 96, 128, 192, ... bytes from them and
+// recycles freed blocks through per-size free lists.  Nothing goes back to the OS before kngt_reset.
 #include "kng_dptable.h"
 
+#include <sys/mman.h>
 #include <sys/stat.h>
+
+#include <atomic>
 
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +36,83 @@ struct Fine {
     kngt_entry *e = nullptr;
     uint32_t n = 0, cap = 0;
 };
+
+// ---- arena allocator: size classes 64, 96, 128, 192, 256, 384, ... bytes (class c: 64 << c/2, times 1.5 when c is odd) ----
+constexpr int MIN_CLASS = 0, MAX_CLASS = 32;          // 64 B .. 4 MiB
+constexpr size_t REGION_MIN = (size_t)64 << 10;       // an arena's first region; each further one doubles ...
+constexpr size_t REGION = (size_t)2 << 20;            // ... up to this (a small table must not cost N_ARENAS x 2 MiB)
+constexpr unsigned ARENA_BITS = 6, N_ARENAS = 1u << ARENA_BITS;
+
+inline size_t class_bytes(int c) { return ((size_t)(c & 1 ? 96 : 64)) << (c >> 1); }
+
+struct Arena {
+    std::atomic_flag lock = ATOMIC_FLAG_INIT;
+    char *cur = nullptr, *end = nullptr;              // bump area of the current region
+    void *free_list[MAX_CLASS + 1] = {};
+    std::vector<std::pair<void *, size_t>> regions;   // for munmap
+    uint64_t bytes = 0;                               // taken from the OS
+};
+
+inline int class_of(size_t bytes) {
+    int c = MIN_CLASS;
+    while (class_bytes(c) < bytes) c++;
+    return c;
+}
+
+struct Locked {
+    Arena &a;
+    explicit Locked(Arena &ar) : a(ar) {
+        while (a.lock.test_and_set(std::memory_order_acquire)) {
+        }
+    }
+    ~Locked() { a.lock.clear(std::memory_order_release); }
+};
+
+void *arena_alloc(Arena &a, int c) {
+    if (c > MAX_CLASS) return nullptr;
+    Locked g(a);
+    if (void *p = a.free_list[c]) {
+        a.free_list[c] = *static_cast<void **>(p);
+        return p;
+    }
+    const size_t sz = class_bytes(c);
+    if ((size_t)(a.end - a.cur) < sz) {
+        // the tail of the old region is recycled as smaller blocks
+        for (int k = MAX_CLASS; k >= MIN_CLASS; k--)
+            while ((size_t)(a.end - a.cur) >= class_bytes(k)) {
+                *reinterpret_cast<void **>(a.cur) = a.free_list[k];
+                a.free_list[k] = a.cur;
+                a.cur += class_bytes(k);
+            }
+        size_t want = REGION_MIN << (a.regions.size() < 5 ? a.regions.size() : 5);
+        if (want < sz) want = sz;
+        void *m = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) return nullptr;
+        if (want >= ((size_t)2 << 20)) (void)madvise(m, want, MADV_HUGEPAGE);
+        a.regions.emplace_back(m, want);
+        a.bytes += want;
+        a.cur = static_cast<char *>(m);
+        a.end = a.cur + want;
+    }
+    void *p = a.cur;
+    a.cur += sz;
+    return p;
+}
+
+void arena_free(Arena &a, void *p, int c) {
+    if (!p) return;
+    Locked g(a);
+    *static_cast<void **>(p) = a.free_list[c];
+    a.free_list[c] = p;
+}
+
+void arena_release(Arena &a) {
+    for (auto &r : a.regions) munmap(r.first, r.second);
+    a.regions.clear();
+    a.cur = a.end = nullptr;
+    for (void *&f : a.free_list) f = nullptr;
+    a.bytes = 0;
+}
 
 struct Bucket {
     Fine *fine = nullptr; // 1 << k arrays, ordered by the top k bits of x[1]
@@ -45,49 +133,55 @@ inline int cmp_x(const uint64_t a[2], const uint64_t b[2]) {
 }
 inline size_t fine_index(uint8_t k, uint64_t x1) { return k ? (size_t)(x1 >> (64 - k)) : 0; }
 
-bool reserve(Fine &f, uint32_t want) {
+inline uint32_t cap_of_class(int c) { return (uint32_t)(class_bytes(c) / sizeof(kngt_entry)); }
+
+bool reserve(Arena &a, Fine &f, uint32_t want) {
     if (want <= f.cap) return true;
-    uint64_t cap = f.cap ? f.cap : 4;
-    while (cap < want) cap += cap / 2 + 4;
-    if (cap > 0xFFFFFFFFULL) return false;
-    void *p = std::realloc(f.e, (size_t)cap * sizeof(kngt_entry));
+    const int c = class_of((size_t)want * sizeof(kngt_entry));
+    kngt_entry *p = static_cast<kngt_entry *>(arena_alloc(a, c));
     if (!p) return false;
-    f.e = static_cast<kngt_entry *>(p);
-    f.cap = (uint32_t)cap;
+    if (f.n) std::memcpy(p, f.e, (size_t)f.n * sizeof(kngt_entry));
+    if (f.e) arena_free(a, f.e, class_of((size_t)f.cap * sizeof(kngt_entry)));
+    f.e = p;
+    f.cap = cap_of_class(c);
     return true;
 }
 
-void free_bucket(Bucket &b) {
+inline int fine_class(uint8_t k) { return class_of(((size_t)1 << k) * sizeof(Fine)); }
+
+void free_bucket(Arena &a, Bucket &b) {
     if (b.fine) {
         const size_t nf = (size_t)1 << b.k;
-        for (size_t i = 0; i < nf; i++) std::free(b.fine[i].e);
-        std::free(b.fine);
+        for (size_t i = 0; i < nf; i++)
+            if (b.fine[i].e) arena_free(a, b.fine[i].e, class_of((size_t)b.fine[i].cap * sizeof(kngt_entry)));
+        arena_free(a, b.fine, fine_class(b.k));
     }
-    b = Bucket();
+    b.fine = nullptr;
+    b.k = 0;
 }
 
 // lay `n` entries (sorted) out over 1 << k fine arrays; the bucket must be empty of storage
-bool build(Bucket &b, uint8_t k, const kngt_entry *sorted, uint32_t n) {
+bool build(Arena &a, Bucket &b, uint8_t k, const kngt_entry *sorted, uint32_t n) {
     const size_t nf = (size_t)1 << k;
-    Fine *fine = static_cast<Fine *>(std::calloc(nf, sizeof(Fine)));
+    Fine *fine = static_cast<Fine *>(arena_alloc(a, fine_class(k)));
     if (!fine) return false;
+    for (size_t q = 0; q < nf; q++) fine[q] = Fine();
+    b.fine = fine;
+    b.k = k;
     uint32_t i = 0;
     while (i < n) {
         const size_t fi = fine_index(k, sorted[i].x[1]);
         uint32_t j = i + 1;
         while (j < n && fine_index(k, sorted[j].x[1]) == fi) j++;
         Fine &f = fine[fi];
-        if (!reserve(f, j - i + 2)) {
-            for (size_t q = 0; q < nf; q++) std::free(fine[q].e);
-            std::free(fine);
+        if (!reserve(a, f, j - i + 2)) {
+            free_bucket(a, b);
             return false;
         }
         std::memcpy(f.e, sorted + i, (size_t)(j - i) * sizeof(kngt_entry));
         f.n = j - i;
         i = j;
     }
-    b.fine = fine;
-    b.k = k;
     return true;
 }
 
@@ -101,14 +195,14 @@ void gather(const Bucket &b, kngt_entry *out) {
     }
 }
 
-bool resplit(Bucket &b, uint8_t k) {
-    std::vector<kngt_entry> all(b.n);
-    gather(b, all.data());
+bool resplit(Arena &a, Bucket &b, uint8_t k, std::vector<kngt_entry> &scratch) {
+    scratch.resize(b.n);
+    gather(b, scratch.data());
     Bucket nb;
-    if (!build(nb, k, all.data(), b.n)) return false; // keep the old layout: still correct, only slower
+    if (!build(a, nb, k, scratch.data(), b.n)) return false; // keep the old layout: still correct, only slower
     nb.n = b.n;
     nb.ref_max = b.ref_max;
-    free_bucket(b);
+    free_bucket(a, b);
     b = nb;
     return true;
 }
@@ -123,7 +217,15 @@ uint8_t k_for(uint32_t n) {
 
 struct kngt_table {
     Bucket b[KNGT_BUCKETS];
+    Arena arena[N_ARENAS];
 };
+
+namespace {
+// the scramble kng_solver's consumer_of() uses: the buckets of an arena belong to one consumer, or to two neighbours
+inline Arena &arena_of(kngt_table *t, uint32_t h) {
+    return t->arena[(((h & (KNGT_BUCKETS - 1)) * 0x9E3779B1u) & (KNGT_BUCKETS - 1)) >> (KNGT_HASH_BITS - ARENA_BITS)];
+}
+} // namespace
 
 extern "C" {
 
@@ -131,7 +233,8 @@ kngt_table *kngt_create(void) { return new (std::nothrow) kngt_table(); }
 
 void kngt_reset(kngt_table *t) {
     if (!t) return;
-    for (Bucket &b : t->b) free_bucket(b);
+    for (Bucket &b : t->b) b = Bucket();
+    for (Arena &a : t->arena) arena_release(a);
 }
 
 void kngt_destroy(kngt_table *t) {
@@ -213,12 +316,8 @@ int kngt_add_entry(kngt_table *t, uint32_t h, const kngt_entry *e, kngt_entry *o
     // +4 step whenever the bucket is within one slot of full at the START of an add (even one that
     // ends as DUPLICATE/COLLISION)
     if (b.ref_max == 0) b.ref_max = 16;
-    if (!b.fine) {
-        Bucket nb;
-        if (!build(nb, 0, nullptr, 0)) return -1;
-        b.fine = nb.fine;
-        b.k = 0;
-    }
+    Arena &ar = arena_of(t, h);
+    if (!b.fine && !build(ar, b, 0, nullptr, 0)) return -1;
     if (b.n && b.n >= b.ref_max - 1) b.ref_max += 4;
 
     Fine &f = b.fine[fine_index(b.k, e->x[1])];
@@ -234,12 +333,15 @@ int kngt_add_entry(kngt_table *t, uint32_t h, const kngt_entry *e, kngt_entry *o
         return KNGT_ADD_COLLISION;
     }
     if (b.n == 0xFFFFFFFFu) return -1; // nbItem is a 32-bit word of the file format
-    if (!reserve(f, f.n + 1)) return -1;
+    if (!reserve(ar, f, f.n + 1)) return -1;
     std::memmove(f.e + lo + 1, f.e + lo, (size_t)(f.n - lo) * sizeof(kngt_entry));
     f.e[lo] = *e;
     f.n++;
     b.n++;
-    if (b.k < K_MAX && b.n > (SPLIT_AVG << b.k)) (void)resplit(b, (uint8_t)(b.k + 2));
+    if (b.k < K_MAX && b.n > (SPLIT_AVG << b.k)) {
+        thread_local std::vector<kngt_entry> scratch;
+        (void)resplit(ar, b, (uint8_t)(b.k + 2), scratch);
+    }
     return KNGT_ADD_OK;
 }
 
@@ -277,12 +379,7 @@ uint64_t kngt_serialised_size(const kngt_table *t) { return (uint64_t)KNGT_BUCKE
 
 uint64_t kngt_memory_bytes(const kngt_table *t) {
     uint64_t m = sizeof(kngt_table);
-    for (const Bucket &b : t->b) {
-        if (!b.fine) continue;
-        const size_t nf = (size_t)1 << b.k;
-        m += nf * sizeof(Fine);
-        for (size_t i = 0; i < nf; i++) m += (uint64_t)b.fine[i].cap * sizeof(kngt_entry);
-    }
+    for (const Arena &a : t->arena) m += a.bytes;
     return m;
 }
 
@@ -322,7 +419,7 @@ int kngt_read(kngt_table *t, FILE *f) {
         // Add() binary-searches the bucket: it must be strictly ascending in (x.limb1, x.limb0) as the reference writes it
         for (uint32_t i = 1; i < n; i++)
             if (cmp_x(buf[i - 1].x, buf[i].x) >= 0) return -1;
-        if (!build(b, k_for(n), buf.data(), n)) return -1;
+        if (!build(arena_of(t, (uint32_t)(&b - t->b)), b, k_for(n), buf.data(), n)) return -1;
         b.n = n;
     }
     return 0;

@@ -503,6 +503,19 @@ void start_consumers(kngs_solver *s, int nc) {
     for (Consumer *c : s->consumers) c->th = std::thread(consumer_main, s, c);
 }
 
+// one table thread sustains 2-5 M inserts per second depending on the table size (tools/dp_ingest_bench); one GPU
+// emits 1.3 M points/s at its own suggested DP size, eight GPUs 85 M/s at theirs (the suggestion shrinks with the
+// population, Kangaroo.cpp:980-993): six threads per GPU, within half of the host's hardware threads
+int default_consumers(int asked, int n_gpus) {
+    if (asked > 0) return asked;
+    const int hw = (int)std::thread::hardware_concurrency();
+    int nc = n_gpus == 1 ? 1 : 6 * n_gpus;
+    if (hw > 0 && nc > hw / 2) nc = hw / 2;
+    if (nc > 64) nc = 64;
+    if (nc < 2 && n_gpus > 1) nc = 2;
+    return nc < 1 ? 1 : nc;
+}
+
 uint64_t draw_seed() {
     std::random_device rd; // the reference seeds from the clock (Timer::getSeed32, main.cpp:177)
     uint64_t v = ((uint64_t)rd() << 32) ^ (uint64_t)rd() ^ (uint64_t)Clock::now().time_since_epoch().count();
@@ -603,18 +616,7 @@ int kngs_start(kngs_solver *s) {
     if (s->started) return fail("already started");
     if (kngs_prepare(s) != 0) return -1;
     const kngs_config &cfg = s->cfg;
-    // one table thread sustains 2-5 M inserts per second depending on the table size (tools/dp_ingest_bench); one GPU
-    // emits 1.3 M points/s at its own suggested DP size, eight GPUs 85 M/s at theirs (the suggestion shrinks with the
-    // population, Kangaroo.cpp:980-993): six threads per GPU, within half of the host's hardware threads
-    int nc = cfg.consumers;
-    if (nc <= 0) {
-        const int hw = (int)std::thread::hardware_concurrency();
-        nc = cfg.n_gpus == 1 ? 1 : 6 * cfg.n_gpus;
-        if (hw > 0 && nc > hw / 2) nc = hw / 2;
-        if (nc > 64) nc = 64;
-        if (nc < 2 && cfg.n_gpus > 1) nc = 2;
-        if (nc < 1) nc = 1;
-    }
+    const int nc = default_consumers(cfg.consumers, cfg.n_gpus);
     start_consumers(s, nc);
     for (Worker *w : s->workers) w->th = std::thread(worker_main, s, w);
     return 0;
@@ -632,7 +634,7 @@ int kngs_start_ingest(kngs_solver *s, int feeders) {
         w->ended = true; // no GPU thread behind it
         s->workers.push_back(w);
     }
-    start_consumers(s, s->cfg.consumers > 0 ? s->cfg.consumers : (2 * feeders > 16 ? 16 : 2 * feeders));
+    start_consumers(s, default_consumers(s->cfg.consumers, feeders));
     return 0;
 }
 

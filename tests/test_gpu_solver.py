@@ -231,3 +231,34 @@ def test_pipeline_keeps_up_with_the_kernel_at_auto_dp(sv):
     assert st["dps_lost"] == 0 and st["wrong_collisions"] == 0
     assert wall_rate > 0.9 * kernel_rate
     s.close()
+
+
+def test_four_engines_one_table_at_the_8gpu_dp_rate(sv):
+    """the shared-table host path under many GPU threads.  Four engines on device 0 (2^21 kangaroos
+    each), DP 9: every launch of every engine delivers 262 144 points -- the per-launch load of the 8-GPU configuration
+    (2^23 kangaroos at DP 11) -- through four GPU threads into ONE table.  The device is time-shared, so the yardstick
+    is the same four-engine job with a DP size that yields no points: the host path may cost at most 10 %."""
+    import kangaroo_amd.hostlib as hl
+
+    start = int("B60E83280258A40F9CDF1649744D730D6E939DE92A2B" + "0" * 20, 16)
+    key = start + 0xC0FFEE123456789ABCD
+    rates = {}
+    for dp in (40, 9):
+        s = sv.Solver(start, start + (1 << 80) - 1, hl.pubkey(key)[1:], gpus=(0, 0, 0, 0), grid=(512, 32), dp=dp, seed=23,
+                      max_launches=48, warmup_launches=2)
+        s.prepare()
+        s.start()
+        assert s.wait(300) == 2
+        st = s.stats()
+        load = s.consumer_load()
+        s.stop()
+        assert st["launches"] == 4 * 48 and st["kangaroos"] == 4 << 21 and st["dps_lost"] == 0 and st["wrong_collisions"] == 0
+        rates[dp] = st["jumps"] / st["seconds"]
+        if dp == 9:
+            expect = (4 << 21) * 64 * 48 >> 9
+            assert 0.97 * expect < st["dps"] < 1.03 * expect
+            assert len(load) >= 2 and sum(load) == st["dps"] and max(load) < 1.2 * st["dps"] / len(load)
+            print(f"4 engines x 262144 DPs/launch: {st['dps'] / st['seconds'] / 1e6:.1f} M DPs/s into one table ({len(load)} consumers), "
+                  f"{rates[9] / 1e9:.2f} GK/s wall vs {rates[40] / 1e9:.2f} GK/s without points")
+        s.close()
+    assert rates[9] > 0.9 * rates[40]

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--dp", type=int, default=14)
     ap.add_argument("--shares", default="2", help="comma list of 1/2/3: waves per SIMD sharing one inversion")
     ap.add_argument("--dsplit", type=int, default=-1, help="-1 auto / 0 / 1: low-word streaming of the distances")
+    ap.add_argument("--jd-bits", type=int, default=40, help="size of the synthetic jump distances: 54+ makes both distance words stream (the non-dsplit kernels)")
     ap.add_argument("--lanes", default="", help="explicit lane counts (ragged groups); overrides --groups")
     a = ap.parse_args()
     gx, gy = (int(v) for v in a.grid.split(","))
@@ -34,7 +35,7 @@ def main():
     x = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
     y = rng.integers(0, 1 << 64, size=(n, 4), dtype=np.uint64)
     d = rng.integers(0, 1 << 62, size=(n, 2), dtype=np.uint64)
-    jd = rng.integers(0, 1 << 40, size=(32, 2), dtype=np.uint64)
+    jd = rng.integers(0, 1 << a.jd_bits, size=(32, 2), dtype=np.uint64)
     jd[:, 1] = 0
     jx = rng.integers(0, 1 << 64, size=(32, 4), dtype=np.uint64)
     jy = rng.integers(0, 1 << 64, size=(32, 4), dtype=np.uint64)
