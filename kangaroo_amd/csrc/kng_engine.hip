@@ -66,7 +66,7 @@ struct WalkArgs {
 #define JT_JD (8 * 32)
 #define JT_WORDS (10 * 32)
 
-// The herd state streams: every vector is read once and written once per jump and not touched again for a
+// The herd state (x, y, d) streams: every vector is read once and written once per jump and not touched again for a
 // whole pass (~0.4 ms, ~1 GB of traffic later).  Non-temporal accesses ("nt": stream through L2 without
 // displacing anything worth keeping) are worth +1.9 % on the walk (profiles/r01_ab_nontemporal.txt).
 #ifndef KNG_NT_LOAD
@@ -110,6 +110,17 @@ KNG_DEV void st_stream64(uint64_t *p, uint64_t v) {
 #else
     *p = v;
 #endif
+}
+// The running products are the exception to the streaming rule: a product written by one pass is the first thing the
+// next pass reads back (passes alternate direction), so the most recent ones are still in L2 / the Infinity Cache.
+// Plain accesses for the S planes: +1.2 % (profiles/r02_ab_micro_variants.txt).
+KNG_DEV fe ld_prod(const v16 *p01, const v16 *p23, size_t i) {
+    const v16 a = p01[i], b = p23[i];
+    return fe{{a.x, a.y, b.x, b.y}};
+}
+KNG_DEV void st_prod(v16 *p01, v16 *p23, size_t i, const fe &v) {
+    p01[i] = make_ulonglong2(v.v[0], v.v[1]);
+    p23[i] = make_ulonglong2(v.v[2], v.v[3]);
 }
 KNG_DEV fe ld_fe(const v16 *p01, const v16 *p23, size_t i) {
     const v16 a = ld_stream(p01 + i), b = ld_stream(p23 + i);
@@ -185,7 +196,7 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
         const uint32_t j = (uint32_t)x.v[0] & (KNG_NB_JUMP - 1);
         const fe dx = fe_sub(x, lds_fe(tab, JT_JX, j));
         acc = g ? fe_mul(acc, dx) : dx;
-        st_fe(a.s01, a.s23, idx, acc);
+        st_prod(a.s01, a.s23, idx, acc);
     }
 
     for (uint32_t step = 0; step < a.nsteps; step++) {
@@ -236,7 +247,7 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
         fe cx = ld_fe(a.x01, a.x23, idx);
         fe cy = ld_fe(a.y01, a.y23, idx);
         v16 cd = DSPLIT ? make_ulonglong2(ld_stream64(dlo + idx), 0) : ld_d(a.d, a.n_kang, idx);
-        fe nb = (G > 1) ? ld_fe(a.s01, a.s23, slot(1)) : fe_one();
+        fe nb = (G > 1) ? ld_prod(a.s01, a.s23, slot(1)) : fe_one();
 
         for (uint32_t k = 0; k < G; k++) {
             // ---- prefetch the next kangaroo and the product after it (before any store) ----
@@ -249,7 +260,7 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
                 ny = ld_fe(a.y01, a.y23, nidx);
                 nd = DSPLIT ? make_ulonglong2(ld_stream64(dlo + nidx), 0) : ld_d(a.d, a.n_kang, nidx);
             }
-            if (k + 2 < G) nnb = ld_fe(a.s01, a.s23, slot(k + 2));
+            if (k + 2 < G) nnb = ld_prod(a.s01, a.s23, slot(k + 2));
 
             // ---- this kangaroo: P += J[x & 31]   (GPUCompute.h:67-94) ----
             const uint32_t j = (uint32_t)cx.v[0] & (KNG_NB_JUMP - 1);
@@ -307,7 +318,7 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
                 const uint32_t j2 = (uint32_t)rx.v[0] & (KNG_NB_JUMP - 1);
                 const fe dx2 = fe_sub(rx, lds_fe(tab, JT_JX, j2));
                 acc = k ? fe_mul(acc, dx2) : dx2;
-                st_fe(a.s01, a.s23, idx, acc);
+                st_prod(a.s01, a.s23, idx, acc);
             }
             cx = nx;
             cy = ny;

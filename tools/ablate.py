@@ -40,9 +40,9 @@ def v_no_s_traffic(files):
     t = files["kng_engine.hip"]
     body = t[t.index("template <int SHARE, bool DSPLIT>\nKNG_DEV void walk_body"):t.index("__global__ void __launch_bounds__(256) kng_walk_kernel")]
     nb = body
-    nb = sub1(nb, "fe nb = (G > 1) ? ld_fe(a.s01, a.s23, slot(1)) : fe_one();", "fe nb = fe{{cx.v[1], cy.v[0], cx.v[3], cy.v[2]}};", 1)
-    nb = sub1(nb, "if (k + 2 < G) nnb = ld_fe(a.s01, a.s23, slot(k + 2));", "if (k + 2 < G) nnb = fe{{nx.v[1], ny.v[0], nx.v[3], ny.v[2]}};", 1)
-    nb = sub1(nb, "                acc = k ? fe_mul(acc, dx2) : dx2;\n                st_fe(a.s01, a.s23, idx, acc);", "                acc = k ? fe_mul(acc, dx2) : dx2;", 1)
+    nb = sub1(nb, "fe nb = (G > 1) ? ld_prod(a.s01, a.s23, slot(1)) : fe_one();", "fe nb = fe{{cx.v[1], cy.v[0], cx.v[3], cy.v[2]}};", 1)
+    nb = sub1(nb, "if (k + 2 < G) nnb = ld_prod(a.s01, a.s23, slot(k + 2));", "if (k + 2 < G) nnb = fe{{nx.v[1], ny.v[0], nx.v[3], ny.v[2]}};", 1)
+    nb = sub1(nb, "                acc = k ? fe_mul(acc, dx2) : dx2;\n                st_prod(a.s01, a.s23, idx, acc);", "                acc = k ? fe_mul(acc, dx2) : dx2;", 1)
     files["kng_engine.hip"] = t.replace(body, nb)
     return files
 
@@ -99,16 +99,35 @@ def v_no_memory(files):
     return files
 
 
-def v_s_plain(files):
-    """product planes through L2 without the non-temporal hint (the rest keeps it)"""
+def v_s_nt(files):
+    """product planes with the non-temporal hint like the rest of the state (the round-1 kernel)"""
     t = files["kng_engine.hip"]
-    t = sub1(t, "KNG_DEV fe ld_fe(const v16 *p01, const v16 *p23, size_t i) {",
-             "KNG_DEV fe ld_fe_plain(const v16 *p01, const v16 *p23, size_t i) {\n    const v16 a = p01[i], b = p23[i];\n    return fe{{a.x, a.y, b.x, b.y}};\n}\n"
-             "KNG_DEV void st_fe_plain(v16 *p01, v16 *p23, size_t i, const fe &v) {\n    p01[i] = make_ulonglong2(v.v[0], v.v[1]);\n    p23[i] = make_ulonglong2(v.v[2], v.v[3]);\n}\n"
-             "KNG_DEV fe ld_fe(const v16 *p01, const v16 *p23, size_t i) {", 1)
     body = t[t.index("template <int SHARE, bool DSPLIT>\nKNG_DEV void walk_body"):t.index("__global__ void __launch_bounds__(256) kng_walk_kernel")]
-    nb = body.replace("ld_fe(a.s01, a.s23,", "ld_fe_plain(a.s01, a.s23,").replace("st_fe(a.s01, a.s23,", "st_fe_plain(a.s01, a.s23,")
+    nb = body.replace("ld_prod(a.s01, a.s23,", "ld_fe(a.s01, a.s23,").replace("st_prod(a.s01, a.s23,", "st_fe(a.s01, a.s23,")
     files["kng_engine.hip"] = t.replace(body, nb)
+    return files
+
+
+def v_setprio(files):
+    """waves 4..7 of the 512-thread block (the younger half, which loses VALU arbitration) run at priority 1"""
+    t = files["kng_engine.hip"]
+    t = sub1(t, "    // pass 0: prefix products of dx in ascending order (GPUCompute.h:52-61 + GPUMath.h:1173-1177)\n",
+             "    if (SHARE > 1 && (threadIdx.x >> 8)) __builtin_amdgcn_s_setprio(1);\n    // pass 0: prefix products of dx in ascending order (GPUCompute.h:52-61 + GPUMath.h:1173-1177)\n", 1)
+    files["kng_engine.hip"] = t
+    return files
+
+
+def v_lds_b64(files):
+    """jump-table words read one ds_read_b64 at a time (hipcc pairs them into ds_read2_b64, whose banking is 32 x 4 B)"""
+    t = files["kng_engine.hip"]
+    t = sub1(t, "    return fe{{tab[base + j], tab[base + 32 + j], tab[base + 64 + j], tab[base + 96 + j]}};",
+             "    typedef __attribute__((address_space(3))) const uint64_t lds_u64;\n"
+             "    const uint32_t addr = (uint32_t)(uintptr_t)(lds_u64 *)tab + 8u * (uint32_t)(base + j);\n"
+             "    uint64_t w0, w1, w2, w3;\n"
+             "    asm volatile(\"ds_read_b64 %0, %4\\n\\tds_read_b64 %1, %4 offset:256\\n\\tds_read_b64 %2, %4 offset:512\\n\\tds_read_b64 %3, %4 offset:768\\n\\ts_waitcnt lgkmcnt(0)\"\n"
+             "                 : \"=&v\"(w0), \"=&v\"(w1), \"=&v\"(w2), \"=&v\"(w3) : \"v\"(addr) : \"memory\");\n"
+             "    return fe{{w0, w1, w2, w3}};", 1)
+    files["kng_engine.hip"] = t
     return files
 
 
@@ -120,7 +139,9 @@ VARIANTS = {
     "no_fold": v_no_fold,
     "no_state_store": v_no_state_store,
     "no_memory": v_no_memory,
-    "s_plain": v_s_plain,
+    "s_nt": v_s_nt,
+    "setprio": v_setprio,
+    "lds_b64": v_lds_b64,
 }
 
 
