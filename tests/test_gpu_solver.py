@@ -262,3 +262,21 @@ def test_four_engines_one_table_at_the_8gpu_dp_rate(sv):
                   f"{rates[9] / 1e9:.2f} GK/s wall vs {rates[40] / 1e9:.2f} GK/s without points")
         s.close()
     assert rates[9] > 0.9 * rates[40]
+
+
+def test_solver_survives_a_dp_buffer_that_is_too_small(sv):
+    """max_found overflow inside the pipeline (GPUEngine.cu:641-648 semantics): with 512 slots for ~16 000 points per
+    launch the surplus is dropped and COUNTED (dps_lost), nothing crashes, the stored points are real and the run ends."""
+    import kangaroo_amd.hostlib as hl
+
+    key = 0xB1E55ED5EEDF00D
+    s = sv.Solver(0, (1 << 64) - 1, hl.pubkey(key)[1:], grid=(8, 128), dp=3, max_found=512, seed=5, max_launches=6, consumers=2)
+    s.start()
+    assert s.wait(120) in (1, 2)
+    st = s.stats()
+    s.stop()
+    assert st["launches"] >= 1 and st["dps"] == 512 * st["launches"]
+    expect = (8 * 128 * 128 * 64 >> 3) * st["launches"]
+    assert 0.9 * expect < st["dps"] + st["dps_lost"] < 1.1 * expect and st["dps_lost"] > 10 * st["dps"]
+    assert st["wrong_collisions"] == 0
+    s.close()
