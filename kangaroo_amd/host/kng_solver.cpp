@@ -505,11 +505,12 @@ void start_consumers(kngs_solver *s, int nc) {
 
 // one table thread sustains 2-5 M inserts per second depending on the table size (tools/dp_ingest_bench); one GPU
 // emits 1.3 M points/s at its own suggested DP size, eight GPUs 85 M/s at theirs (the suggestion shrinks with the
-// population, Kangaroo.cpp:980-993): six threads per GPU, within half of the host's hardware threads
+// population, Kangaroo.cpp:980-993) -- which 16 threads absorb on the GPU box's host (profiles/r02_dp_ingest_arena.txt):
+// four threads per GPU, within half of the host's hardware threads
 int default_consumers(int asked, int n_gpus) {
     if (asked > 0) return asked;
     const int hw = (int)std::thread::hardware_concurrency();
-    int nc = n_gpus == 1 ? 1 : 6 * n_gpus;
+    int nc = n_gpus == 1 ? 1 : 4 * n_gpus;
     if (hw > 0 && nc > hw / 2) nc = hw / 2;
     if (nc > 64) nc = 64;
     if (nc < 2 && n_gpus > 1) nc = 2;
