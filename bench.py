@@ -204,17 +204,18 @@ def bench_multi(args, ranks, n_gpus):
         from kangaroo_amd import solver as sv
 
         k.load_library()
-        if k.device_count() < n_gpus:
-            raise SystemExit(f"--gpus {n_gpus} but only {k.device_count()} HIP devices are visible")
-        info = k.device_info(0)
+        devices = tuple(int(v) for v in args.devices.split(",")) if args.devices else tuple(range(n_gpus))
+        if len(devices) != n_gpus or max(devices) >= k.device_count():
+            raise SystemExit(f"--gpus {n_gpus}: devices {devices} but {k.device_count()} HIP devices are visible")
+        info = k.device_info(devices[0])
         if args.grid:
             gx, gy = (int(v) for v in args.grid.split(","))
         else:
-            gx, gy = k.default_grid(0)
+            gx, gy = k.default_grid(devices[0])
         n = gx * gy * k.KNG_GRP_SIZE
         dp = hl.suggest_dp(RANGE_POWER, n * n_gpus)  # totalRW of Kangaroo.cpp:946-993
         _, kx, ky = hl.pubkey(KEY)
-        s = sv.Solver(RANGE_START, RANGE_START + (1 << RANGE_POWER) - 1, (kx, ky), gpus=tuple(range(n_gpus)), grid=(gx, gy), dp=dp,
+        s = sv.Solver(RANGE_START, RANGE_START + (1 << RANGE_POWER) - 1, (kx, ky), gpus=devices, grid=(gx, gy), dp=dp,
                       seed=0xBEEF, max_launches=args.steps, warmup_launches=args.warmup)
         t0 = time.time()
         s.prepare()  # engines, herds (built on the GPUs), W discarded launches per GPU
@@ -227,7 +228,7 @@ def bench_multi(args, ranks, n_gpus):
         for g in range(n_gpus):
             gs = s.gpu_stats(g)
             kms = gs["kernel_ms_sum"] / max(1, gs["launches"])
-            per_gpu.append({"gpu": g, "launches": gs["launches"], "kernel_ms": round(kms, 3),
+            per_gpu.append({"gpu": g, "device": devices[g], "launches": gs["launches"], "kernel_ms": round(kms, 3),
                             "kernel_rate": round(gs["kangaroos"] * k.KNG_NB_RUN / (kms * 1e-3) / 1e6, 1)})
         load = s.consumer_load()
         s.stop()
@@ -273,6 +274,7 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="skip the end-to-end host-pipeline sample (N=1 only)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary kernel-rate lines (N=1 only)")
     ap.add_argument("--host-herd", action="store_true", help="build the herd on the host and upload it (default: on the GPU)")
+    ap.add_argument("--devices", default="", help="N > 1: explicit device list, e.g. 0,0 to exercise the multi-GPU path on one device (default 0..N-1)")
     args = ap.parse_args()
 
     # torch is plumbing here: rendezvous/barrier over RCCL and the cross-rank max of the timings

@@ -280,3 +280,23 @@ def test_solver_survives_a_dp_buffer_that_is_too_small(sv):
     assert 0.9 * expect < st["dps"] + st["dps_lost"] < 1.1 * expect and st["dps_lost"] > 10 * st["dps"]
     assert st["wrong_collisions"] == 0
     s.close()
+
+
+def test_bench_multi_gpu_mode_on_one_device(sv):
+    """`bench.py --gpus 2` = ONE process over two engines and one shared table (the form the driver's scaling run uses, there
+    under torchrun with one engine per device).  Here both engines sit on device 0 (`--devices 0,0`): the JSON line must carry the
+    contract's fields, per-GPU kernel figures, and a whole-job rate that is not above the sum of the kernel rates."""
+    import json
+    import sys
+
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0", "--steps", "6", "--warmup", "1",
+                          "--grid", "128,128"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["warmup"] == 1 and line["unit"] == "MK/s" and line["scaling"] == "weak"
+    assert line["config"]["dp"] == 15 and line["config"]["kangaroos_per_gpu"] == 128 * 128 * 128  # DP from the population of both
+    assert [p["launches"] for p in line["per_gpu"]] == [6, 6] and all(p["kernel_ms"] > 0 for p in line["per_gpu"])
+    assert 0 < line["value"] <= 1.02 * line["kernel_rate_sum"]
+    assert line["roofline"]["kernel"].startswith("kng_walk") and 0 < line["roofline"]["frac"] < 1
+    assert line["config"]["dps_lost"] == 0
