@@ -111,9 +111,10 @@ KNG_DEV void st_stream64(uint64_t *p, uint64_t v) {
     *p = v;
 #endif
 }
-// The running products are the exception to the streaming rule: a product written by one pass is the first thing the
-// next pass reads back (passes alternate direction), so the most recent ones are still in L2 / the Infinity Cache.
-// Plain accesses for the S planes: +1.2 % (profiles/r02_ab_micro_variants.txt).
+// The running products are the exception to the streaming rule: a pass overwrites product slot k one iteration after it
+// read that very slot (as the neighbour product of the kangaroo before); with the streaming hint the read does not keep
+// the line and the write misses L2.  Plain accesses for the S planes: +17 % L2 hits, +1.2 % walk rate
+// (profiles/r02_pmc_tcc_product_planes.txt, profiles/r02_ab_micro_variants.txt).
 KNG_DEV fe ld_prod(const v16 *p01, const v16 *p23, size_t i) {
     const v16 a = p01[i], b = p23[i];
     return fe{{a.x, a.y, b.x, b.y}};
