@@ -108,6 +108,32 @@ def v_s_nt(files):
     return files
 
 
+def v_s_ld_plain_st_nt(files):
+    """product planes: plain loads, non-temporal stores"""
+    t = files["kng_engine.hip"]
+    body = t[t.index("template <int SHARE, bool DSPLIT>\nKNG_DEV void walk_body"):t.index("__global__ void __launch_bounds__(256) kng_walk_kernel")]
+    nb = body.replace("st_prod(a.s01, a.s23,", "st_fe(a.s01, a.s23,")
+    files["kng_engine.hip"] = t.replace(body, nb)
+    return files
+
+
+def v_s_ld_nt_st_plain(files):
+    """product planes: non-temporal loads, plain stores"""
+    t = files["kng_engine.hip"]
+    body = t[t.index("template <int SHARE, bool DSPLIT>\nKNG_DEV void walk_body"):t.index("__global__ void __launch_bounds__(256) kng_walk_kernel")]
+    nb = body.replace("ld_prod(a.s01, a.s23,", "ld_fe(a.s01, a.s23,")
+    files["kng_engine.hip"] = t.replace(body, nb)
+    return files
+
+
+def v_xy_st_plain(files):
+    """x, y: non-temporal loads, plain stores"""
+    t = files["kng_engine.hip"]
+    t = sub1(t, "#define KNG_NT_STORE 1", "#define KNG_NT_STORE 0", 1)
+    files["kng_engine.hip"] = t
+    return files
+
+
 def v_setprio(files):
     """waves 4..7 of the 512-thread block (the younger half, which loses VALU arbitration) run at priority 1"""
     t = files["kng_engine.hip"]
@@ -140,6 +166,9 @@ VARIANTS = {
     "no_state_store": v_no_state_store,
     "no_memory": v_no_memory,
     "s_nt": v_s_nt,
+    "s_ld_plain_st_nt": v_s_ld_plain_st_nt,
+    "s_ld_nt_st_plain": v_s_ld_nt_st_plain,
+    "xy_st_plain": v_xy_st_plain,
     "setprio": v_setprio,
     "lds_b64": v_lds_b64,
 }
