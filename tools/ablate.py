@@ -134,6 +134,15 @@ def v_xy_st_plain(files):
     return files
 
 
+def v_stagger(files):
+    """workgroups start up to 7/8 of a step apart, so that the chip is never all-walking or all-inverting at once"""
+    t = files["kng_engine.hip"]
+    t = sub1(t, "    // pass 0: prefix products of dx in ascending order (GPUCompute.h:52-61 + GPUMath.h:1173-1177)\n",
+             "    if (SHARE > 1) for (uint32_t w = 0; w < 12u * (blockIdx.x & 7u); w++) __builtin_amdgcn_s_sleep(127);\n    // pass 0: prefix products of dx in ascending order (GPUCompute.h:52-61 + GPUMath.h:1173-1177)\n", 1)
+    files["kng_engine.hip"] = t
+    return files
+
+
 def v_setprio(files):
     """waves 4..7 of the 512-thread block (the younger half, which loses VALU arbitration) run at priority 1"""
     t = files["kng_engine.hip"]
@@ -170,6 +179,7 @@ VARIANTS = {
     "s_ld_nt_st_plain": v_s_ld_nt_st_plain,
     "xy_st_plain": v_xy_st_plain,
     "setprio": v_setprio,
+    "stagger": v_stagger,
     "lds_b64": v_lds_b64,
 }
 
