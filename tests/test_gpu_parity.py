@@ -401,8 +401,6 @@ def test_allocation_failure_is_reported_not_fatal(kng):
     allocation error code and leaks nothing -- a normal engine can be created right after."""
     with pytest.raises(kng.EngineError, match=r"error -2: herd state"):
         kng.GPUEngine(1 << 16, 1024, 0, 65536)
-    with pytest.raises(kng.EngineError, match=r"error -2: (dp items|pinned dp items)"):
-        kng.GPUEngine(2, 2, 0, 0xFFFFFFFF)  # 2^32 DP slots x 64 B x 2 buffers
     with kng.GPUEngine(2, 2, 0, 1024) as eng:
         assert eng.nbKangaroo == 512
 
