@@ -395,8 +395,7 @@ int kngt_write(const kngt_table *t, FILE *f) {
     return 0;
 }
 
-int kngt_read(kngt_table *t, FILE *f) {
-    kngt_reset(t);
+static int read_buckets(kngt_table *t, FILE *f) {
     // a bucket cannot announce more entries than the file has bytes left (a truncated or corrupt file must fail,
     // not allocate); unknown size (a pipe) falls back to the 32-bit word itself
     uint64_t remaining = UINT64_MAX;
@@ -423,6 +422,13 @@ int kngt_read(kngt_table *t, FILE *f) {
         b.n = n;
     }
     return 0;
+}
+
+int kngt_read(kngt_table *t, FILE *f) {
+    kngt_reset(t);
+    const int rc = read_buckets(t, f);
+    if (rc != 0) kngt_reset(t); // never leave half a table behind a failed load
+    return rc;
 }
 
 } // extern "C"
