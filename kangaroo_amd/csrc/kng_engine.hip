@@ -577,7 +577,7 @@ static void decide_dsplit(kng_engine *h) {
 extern "C" {
 
 const char *kng_last_error(void) { return g_err.c_str(); }
-const char *kng_version(void) { return "kangaroo_hip 0.1 (gfx950)"; }
+const char *kng_version(void) { return "kangaroo_hip 0.2 (gfx950)"; }
 
 int kng_device_count(void) {
     int n = 0;
