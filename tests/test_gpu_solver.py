@@ -300,3 +300,68 @@ def test_bench_multi_gpu_mode_on_one_device(sv):
     assert 0 < line["value"] <= 1.02 * line["kernel_rate_sum"]
     assert line["roofline"]["kernel"].startswith("kng_walk") and 0 < line["roofline"]["frac"] < 1
     assert line["config"]["dps_lost"] == 0
+
+
+def test_restore_into_a_different_number_of_gpus(sv, tmp_path, orc):
+    """FetchWalks (Kangaroo.cpp:646-668): a work file with fewer kangaroos than the GPUs hold restores what it has and the
+    rest is created; one with more fills the herd and the surplus stays in the file.  The restored kangaroos are the
+    saved ones: one launch later they stand where the oracle walks them."""
+    import kangaroo_amd.hostlib as hl
+
+    rp = 70
+    start = 0x7A00000000000000000000
+    kxy = hl.pubkey(start + 0x2B1B2C3D4E5F60718)[1:]
+    grid = (8, 128)
+    n = grid[0] * grid[1] * 128
+    f1, f2 = str(tmp_path / "one.work"), str(tmp_path / "two.work")
+    a = sv.Solver(start, start + (1 << rp) - 1, kxy, grid=grid, dp=6, seed=31, max_launches=2)
+    a.start()
+    assert a.wait(120) == 2
+    a.save(f1, True)
+    sa = a.stats()
+    a.stop()
+    a.close()
+    assert sa["herd_created"] == n and sa["herd_loaded"] == 0 and sa["seed"] == 31
+    _, n1, (x1, y1, d1) = sv.read_workfile(f1, None)
+    assert n1 == n
+
+    # two engines: the first gets the file's herd, the second a fresh one
+    b = sv.Solver(start, start + (1 << rp) - 1, kxy, gpus=(0, 0), grid=grid, dp=-1, seed=32, max_launches=1)
+    b.load(f1)
+    b.start()
+    assert b.wait(120) == 2
+    b.save(f2, True)
+    sb = b.stats()
+    b.stop()
+    b.close()
+    assert sb["herd_loaded"] == n and sb["herd_created"] == n and sb["kangaroos"] == 2 * n
+    assert sb["jumps"] == sa["jumps"] + 2 * n * 64 and sb["wrong_collisions"] == 0
+    _, n2, (x2, y2, d2) = sv.read_workfile(f2, None)
+    assert n2 == 2 * n
+    woff = ((1 << rp) - 1) >> 1
+    jd, jx, jy, _ = orc.jump_table(rp)
+    od = hl.to_device_distances(d1, woff)
+    ox, oy = x1.copy(), y1.copy()
+    orc.walk(ox, oy, od, 64, jd, jx, jy, orc.dp_mask(6), dp_cap=0)
+    same = np.all(x2[:n] == ox, axis=1)  # kangaroos replaced after a same-herd collision differ by design
+    assert same.sum() >= n - sb["same_herd"] - 8
+    assert np.array_equal(y2[:n][same], oy[same]) and np.array_equal(hl.to_device_distances(d2[:n], woff)[same], od[same])
+    # the created half is a valid herd too: every sampled kangaroo sits at its distance
+    for i in range(n, 2 * n, 4099):
+        dt = hl.to_int(d2[i])
+        _, px, py = hl.pubkey(dt % N_ORDER_) if i % 2 == 0 else (0, None, None)
+        if i % 2 == 0:
+            assert (px, py) == (hl.to_int(x2[i]), hl.to_int(y2[i]))
+
+    # a smaller herd than the file holds: filled from the file, nothing created
+    c = sv.Solver(start, start + (1 << rp) - 1, kxy, grid=(4, 128), dp=-1, seed=33, max_launches=1)
+    c.load(f2)
+    c.start()
+    assert c.wait(120) == 2
+    sc = c.stats()
+    c.stop()
+    c.close()
+    assert sc["herd_loaded"] == 4 * 128 * 128 and sc["herd_created"] == 0
+
+
+N_ORDER_ = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
