@@ -181,6 +181,30 @@ class Oracle:
         return x, y
 
 
+def _create_herd_parallel(self, d4, kx: int, ky: int, threads=None, chunk=1 << 12):
+    """create_herd (tame d*G at even, wild K + d*G at odd indices) over a thread pool: points are independent"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    n = d4.shape[0]
+    d4 = np.ascontiguousarray(d4)
+    x = np.zeros((n, 4), dtype=np.uint64)
+    y = np.zeros((n, 4), dtype=np.uint64)
+    fn = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, _U64P, _U64P)(("orc_create_herd", self.lib))
+    kxl, kyl = to_limbs(kx), to_limbs(ky)
+    addr = lambda a, i: C.c_void_p(a.ctypes.data + i * a.strides[0])  # noqa: E731
+
+    def one(c0):
+        m = min(chunk, n - c0)
+        fn(addr(x, c0), addr(y, c0), addr(d4, c0), m, c0 & 1, kxl, kyl)
+
+    with ThreadPoolExecutor(threads or min(os.cpu_count() or 1, 256)) as ex:
+        list(ex.map(one, range(0, n, chunk)))
+    return x, y
+
+
+Oracle.create_herd_parallel = _create_herd_parallel
+
+
 def build_oracle() -> str:
     """Compile oracle/liboracle.so (gcc, <1 s).  Building the checker is not using it."""
     subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])

@@ -3,6 +3,7 @@
  * See kng_oracle.h for the contract and the reference citations.  Plain C11 + __int128.
  * Parity: PINNED against oracle/_ref/refprobe (reference SECPK1 objects) and tests/golden.
  */
+#include <pthread.h>
 #include "kng_oracle.h"
 
 #include <math.h>
@@ -273,19 +274,21 @@ static void apt_add(apt_t *r, const apt_t *a, const apt_t *b) {
 /* 32 x 255 window table of G, the shape of the reference's GTable (SECP256K1.cpp:40-58):
  * gtab[i][j] = (j+1) * 256^i * G */
 static apt_t (*gtab)[255];
-static void gtab_init(void) {
-    if (gtab) return;
-    gtab = malloc(32 * sizeof *gtab);
+static pthread_once_t gtab_once = PTHREAD_ONCE_INIT; /* tests walk and verify herds from many threads */
+static void gtab_build(void) {
+    apt_t(*tab)[255] = malloc(32 * sizeof *tab);
     apt_t base;
     base.inf = 0;
     memcpy(base.x, GX, 32);
     memcpy(base.y, GY, 32);
     for (int i = 0; i < 32; i++) {
-        gtab[i][0] = base;
-        for (int j = 1; j < 255; j++) apt_add(&gtab[i][j], &gtab[i][j - 1], &base);
-        apt_add(&base, &gtab[i][254], &base); /* 256 * base */
+        tab[i][0] = base;
+        for (int j = 1; j < 255; j++) apt_add(&tab[i][j], &tab[i][j - 1], &base);
+        apt_add(&base, &tab[i][254], &base); /* 256 * base */
     }
+    gtab = tab;
 }
+static void gtab_init(void) { pthread_once(&gtab_once, gtab_build); }
 
 int orc_pubkey_add(uint64_t x[4], uint64_t y[4], const uint64_t k[4], const uint64_t qx[4],
                    const uint64_t qy[4]) {

@@ -396,6 +396,29 @@ def test_bench_config_total_parity(kng, orc, dsplit):
         assert np.array_equal(a, b)
 
 
+def test_device_built_herd_at_full_size(kng, orc):
+    """kng_build_herd at the bench configuration (2^23 kangaroos): every 7th kangaroo -- 1.2 million, both types, every lane
+    and batch position -- sits at d*G (tame) / K' + d*G (wild) for the distance the engine reports, recomputed by the oracle
+    over a thread pool; all distances are in range and practically all distinct."""
+    import kangaroo_amd.hostlib as hl
+
+    rp, gx, gy = 80, 512, 128
+    n = gx * gy * 128
+    _, kx, ky = hl.pubkey((1 << 79) + 0x5EED5EED5EED)
+    jd, jx, jy, _ = hl.jump_table(rp)
+    with kng.GPUEngine(gx, gy, 0, 1 << 17) as eng:
+        eng.SetParams(hl.dp_mask(14), jd, jx, jy)
+        woff = eng.CreateHerdOnDevice(rp, (kx, ky), seed=0xF00D)
+        x, y, dd = eng.GetKangaroos(raw=True)
+    assert woff == ((1 << rp) - 1) >> 1
+    assert np.all(dd[:, 1] < np.uint64(1 << (rp - 64))) and len(np.unique(dd[:, 0])) > 0.999 * n
+    idx = np.arange(0, n, 7, dtype=np.uint64)
+    d_true = hl.to_true_distances(np.ascontiguousarray(dd[idx]), woff, idx)
+    # an odd stride: the sample alternates tame / wild by position, like a herd (Kangaroo.cpp:699), so create_herd applies
+    ox, oy = orc.create_herd_parallel(d_true, kx, ky)
+    assert np.array_equal(ox, x[idx]) and np.array_equal(oy, y[idx])
+
+
 def test_allocation_failure_is_reported_not_fatal(kng):
     """KNG_E_ALLOC: a herd that cannot fit the device (2^33 kangaroos, 960 GB of state) fails kng_create with the
     allocation error code and leaks nothing -- a normal engine can be created right after."""
