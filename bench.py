@@ -115,8 +115,6 @@ def cpu_baseline(seconds: float = 20.0) -> dict:
 def _kernel_name(eng) -> str:
     """Name of the walk kernel the engine launches with its current options (as rocprofv3 prints it)."""
     share, ds = eng.get_option("share"), eng.get_option("dsplit")
-    if share == 1:
-        return "kng_walk_dsplit_kernel" if ds else "kng_walk_kernel"
     return f"kng_walk_share_kernel<{share}, {'true' if ds else 'false'}>"
 
 

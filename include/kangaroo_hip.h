@@ -145,7 +145,7 @@ int kng_last_kernel_ms(const kng_engine *h, float *ms);
  *            walk ceil or floor of herd/lanes kangaroos)
  *   "block"  threads per workgroup (multiple of 64)
  *   "share"  waves of one SIMD that share one modular inversion per jump: 1 = none (256-thread blocks),
- *            2 (default) / 3 = waves w, w+4(, w+8) of a 512/768-thread block ("block" is then ignored)
+ *            2 (default) = waves w, w+4 of a 512-thread block ("block" is then ignored)
  *   "dsplit" -1 (default): stream only the low word of the 128-bit distances through HBM when every jump
  *            distance given to kng_set_params is below 2^50 (the high word is then updated on the rare carry);
  *            0 = never, 1 = whenever the table allows it (all high words zero).  Reads back 0/1 = in effect.

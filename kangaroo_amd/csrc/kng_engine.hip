@@ -169,8 +169,8 @@ KNG_DEV void emit_dp(bool is_dp, const fe &x, const v16 &d, uint64_t kidx, const
 
 // The hot kernel.  Replaces comp_kangaroos/ComputeKangaroos (GPUEngine.cu:35-40, GPUCompute.h:22-117).
 //
-// SHARE > 1 (256*SHARE-thread blocks, option "share"): the SHARE waves that occupy one SIMD (waves w, w+4,
-// .. of the block) share ONE inversion per jump.  Waves w+4.. park their lane products in LDS and wait at
+// SHARE = 2 (512-thread blocks, option "share"): the two waves that occupy one SIMD (waves w, w+4
+// of the block) share ONE inversion per jump.  Waves w+4.. park their lane products in LDS and wait at
 // the barrier; wave w inverts the product of all chains and hands the individual inverses back, e.g.
 //     i = 1/(acc*pb) ;  1/acc = i*pb ;  1/pb = i*acc          (3 extra multiplications per lane pair)
 // Two co-resident waves inverting side by side need ~2 x 55K SIMD cycles per jump of the pair; one wave
@@ -330,24 +330,13 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
     }
 }
 
-__global__ void __launch_bounds__(256) kng_walk_kernel(const WalkArgs a) {
-    __shared__ uint64_t tab[JT_WORDS];
-    for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
-    __syncthreads();
-    walk_body<1, false>(a, tab, nullptr);
-}
-
-__global__ void __launch_bounds__(256) kng_walk_dsplit_kernel(const WalkArgs a) {
-    __shared__ uint64_t tab[JT_WORDS];
-    for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
-    __syncthreads();
-    walk_body<1, true>(a, tab, nullptr);
-}
-
+// SHARE = 1: 256-thread blocks, every wave inverts for itself (small herds, option "share").  SHARE = 2: 512-thread
+// blocks, waves w and w+4 share one inversion.  (Round 2 also carried SHARE = 3 and two non-template twins of <1,.>;
+// share 3 lost at every herd size, profiles/r02_group_share_sweep.txt, and was dropped in round 3.)
 template <int SHARE, bool DSPLIT>
 __global__ void __launch_bounds__(256 * SHARE) kng_walk_share_kernel(const WalkArgs a) {
     __shared__ uint64_t tab[JT_WORDS];
-    __shared__ v16 xch[512 * (SHARE - 1)];
+    __shared__ v16 xch[SHARE > 1 ? 512 * (SHARE - 1) : 1];
     for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
     __syncthreads();
     walk_body<SHARE, DSPLIT>(a, tab, xch);
@@ -477,7 +466,7 @@ __global__ void kng_patch_kernel(v16 *x01, v16 *x23, v16 *y01, v16 *y23, v16 *d,
 }
 
 // device self-test of the primitives (replaces the compiled-out check_gpu, GPUEngine.cu:43-92)
-__global__ void kng_fieldop_kernel(int op, const uint64_t *a, const uint64_t *b, uint64_t *r, uint64_t n) {
+__global__ void __launch_bounds__(64) kng_fieldop_kernel(int op, const uint64_t *a, const uint64_t *b, uint64_t *r, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const fe x{{a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]}};
@@ -733,7 +722,7 @@ int kng_set_option(kng_engine *h, const char *key, int64_t value) {
         h->dsplit = (int)value;
         decide_dsplit(h);
     } else if (k == "share") {
-        if (value < 1 || value > 3) return fail(KNG_E_ARG, "share must be 1, 2 or 3");
+        if (value < 1 || value > 2) return fail(KNG_E_ARG, "share must be 1 or 2");
         h->share = (int)value;
     } else {
         return fail(KNG_E_ARG, "unknown option '%s'", key);
@@ -926,12 +915,9 @@ int kng_launch(kng_engine *h) {
     if (h->share == 2) {
         if (ds) hipLaunchKernelGGL((kng_walk_share_kernel<2, true>), dim3((h->lanes + 511) / 512), dim3(512), 0, h->walk, a);
         else hipLaunchKernelGGL((kng_walk_share_kernel<2, false>), dim3((h->lanes + 511) / 512), dim3(512), 0, h->walk, a);
-    } else if (h->share == 3) {
-        if (ds) hipLaunchKernelGGL((kng_walk_share_kernel<3, true>), dim3((h->lanes + 767) / 768), dim3(768), 0, h->walk, a);
-        else hipLaunchKernelGGL((kng_walk_share_kernel<3, false>), dim3((h->lanes + 767) / 768), dim3(768), 0, h->walk, a);
     } else {
-        if (ds) hipLaunchKernelGGL(kng_walk_dsplit_kernel, dim3(blocks), dim3(h->block), 0, h->walk, a);
-        else hipLaunchKernelGGL(kng_walk_kernel, dim3(blocks), dim3(h->block), 0, h->walk, a);
+        if (ds) hipLaunchKernelGGL((kng_walk_share_kernel<1, true>), dim3(blocks), dim3(h->block), 0, h->walk, a);
+        else hipLaunchKernelGGL((kng_walk_share_kernel<1, false>), dim3(blocks), dim3(h->block), 0, h->walk, a);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev_stop[s], h->walk));

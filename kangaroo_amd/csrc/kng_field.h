@@ -84,6 +84,10 @@ KNG_DEV fe fe_sub(const fe &a, const fe &b) {
 } // namespace kng
 
 #include "kng_mul32.h"
+#ifndef KNG_USE_MULASM
+#define KNG_USE_MULASM 1 // product + fold as one scheduled asm statement (kng_mulasm.h); 0 = the per-column form of rounds 1-2
+#endif
+#include "kng_mulasm.h"
 
 namespace kng {
 
@@ -224,8 +228,23 @@ KNG_DEV fe fe_mul_c32(const fe &a, const fe &b) {
     uint32_t x[8], y[8], w[16];
     fe_to32(x, a);
     fe_to32(y, b);
+#if KNG_MULASM && KNG_USE_MULASM
+    // one scheduled statement for product and fold; `rare` collects the lanes for which the short fold is not exact
+    // (wave-uniform test: an SGPR lane mask), in which case the wave multiplies again with every carry rippled
+    uint32_t r[8];
+    uint64_t rare = 0;
+    mul_fold_asm(r, x, y, rare);
+    if (__builtin_expect(rare != 0, 0)) {
+        KNG_RARE_PATH();
+        mul_wide32(w, x, y);
+        return fe_fold32_full(w);
+    }
+    return fe{{(uint64_t)r[0] | ((uint64_t)r[1] << 32), (uint64_t)r[2] | ((uint64_t)r[3] << 32),
+               (uint64_t)r[4] | ((uint64_t)r[5] << 32), (uint64_t)r[6] | ((uint64_t)r[7] << 32)}};
+#else
     mul_wide32(w, x, y);
     return fe_fold32_checked(w);
+#endif
 }
 
 // a^2 with the 36-MAD squaring schedule (sqr_wide32) -- same 512-bit integer, same fold

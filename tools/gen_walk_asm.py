@@ -1,0 +1,368 @@
+#!/usr/bin/env python3
+"""Generate kangaroo_amd/csrc/kng_walk_asm.h: the walk kernel's per-kangaroo loop (the k-loop of walk_body,
+kng_engine.hip) as ONE scheduled gfx950 asm statement per distance layout.
+
+What the loop does per iteration is exactly walk_body's iteration (GPUCompute.h:67-105 of the reference): P += J[x & 31]
+with the running batch inverse, d += jD, DP test and wave-compacted DP records, prefix product of the next jump's dx.
+What changes is who schedules it: tools/kasm.py list-schedules the whole iteration (six products, seven subtractions,
+LDS reads, prefetch loads) as one dependency graph, so carry chains are padded by independent multiplies instead of
+s_nop, operands stay in 32-bit registers from load to store (no repacking moves), and the prefetch registers rotate with
+one move per word instead of the compiler's copies.
+
+Exact-path protocol.  The short forms (single-chain fold, two-limb borrow fix-up, low-word distance add) flag the lanes
+for which they are not exact in an SGPR mask.  When any lane of the wave is flagged, the iteration is abandoned BEFORE
+anything is stored: the statement returns with k = that iteration, `inv`/`acc` untouched, and the C++ caller runs this
+one iteration with the generic code (walk_one in kng_engine.hip), then re-enters at k + 1.
+
+Interface (see KNG_WALK_ASM_LOOP at the end of the generated header):
+    in/out  inv[8], acc[8]   32-bit limbs of the running inverse / running prefix product
+    in/out  k                next iteration to execute (SGPR); == G on normal completion
+    in/out  voff             byte offset of kangaroo slot(k) in a 16-byte plane ((slot * L + t) * 16)
+    in      args             device pointer to a WalkAsmArgs block (plane bases, DP buffer, mask)
+    in      stride           +-L * 16: byte distance from slot(k) to slot(k+1) in a 16-byte plane
+    in      G                kangaroos of this lane (wave-uniform)
+    in      lds_tab          LDS byte address of the limb-major jump table
+Planes are addressed as SGPR base + 32-bit VGPR byte offset, so a herd is limited to 2^28 kangaroos on this path
+(4 GiB per 16-byte plane); the engine keeps the C++ loop for anything larger.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kasm  # noqa: E402
+import kfield  # noqa: E402
+from kasm import EXEC, Asm, Tup  # noqa: E402
+
+# WalkAsmArgs layout (kng_engine.hip)
+OFF_PLANES = 0x00  # x01 x23 y01 y23 dlo dhi s01 s23 : 8 pointers
+OFF_DP = 0x40  # dp_mask(8) dp_count(8) dp_items(8) max_found(4) pad(4)
+
+NOPS = {"x": 0}
+
+
+class Loop:
+    def __init__(self, dsplit: bool):
+        self.dsplit = dsplit
+        A = self.A = Asm()
+        # ---- operands (compiler-allocated)
+        self.INV = [A.operand("v", f"%{i}") for i in range(8)]
+        self.ACC = [A.operand("v", f"%{8 + i}") for i in range(8)]
+        self.k = A.operand("s", "%16")
+        self.voff = A.operand("v", "%17")
+        self.args = A.operand("s", "%18", 2)
+        self.stride = A.operand("s", "%19")
+        self.G = A.operand("s", "%20")
+        self.ldstab = A.operand("s", "%21")
+        # ---- pinned state
+        self.planes = A.st("planes", 16, pinned=True)  # 8 pointers
+        self.dpblk = A.st("dpblk", 8, pinned=True)  # mask, count ptr, items ptr, max_found, pad
+        self.P = {n: self.planes.sub(2 * i, 2) for i, n in enumerate(["x01", "x23", "y01", "y23", "dlo", "dhi", "s01", "s23"])}
+        self.dp_mask_lo, self.dp_mask_hi = self.dpblk[0], self.dpblk[1]
+        self.dp_count = self.dpblk.sub(2, 2)
+        self.dp_items = self.dpblk.sub(4, 2)
+        self.max_found = self.dpblk[6]
+        self.k977 = A.s("k977", pinned=True)
+        self.v977 = A.v("v977", pinned=True)
+        self.rare = A.st("rare", 2, pinned=True)
+        q = lambda n: A.vt(n, 4, pinned=True)  # noqa: E731
+        self.CX, self.CY = [q("cx0"), q("cx1")], [q("cy0"), q("cy1")]
+        self.NX, self.NY = [q("nx0"), q("nx1")], [q("ny0"), q("ny1")]
+        self.NB, self.NNB = [q("nb0"), q("nb1")], [q("nnb0"), q("nnb1")]
+        self.CD, self.ND = q("cd"), q("nd")  # distance: (lo0, lo1, hi0, hi1); DSPLIT streams only the low pair
+        self.F = kfield.Field(A, self.k977, self.rare)
+
+    @staticmethod
+    def limbs(quads):
+        return [r for qd in quads for r in qd.regs]
+
+    # ------------------------------------------------------------------------------------------------
+    def load_fe(self, quads, voff, p0, p1, nt):
+        self.A.global_load(4, quads[0], voff, self.P[p0], nt=nt)
+        self.A.global_load(4, quads[1], voff, self.P[p1], nt=nt)
+
+    def load_d(self, quad, voff8):
+        A = self.A
+        A.global_load(2, quad.sub(0, 2), voff8, self.P["dlo"])
+        if not self.dsplit:
+            A.global_load(2, quad.sub(2, 2), voff8, self.P["dhi"])
+
+    def set_one(self, quads):
+        A = self.A
+        for i, r in enumerate(self.limbs(quads)):
+            A.v_mov_b32(r, 1 if i == 0 else 0)
+
+    def build(self):
+        A, F = self.A, self.F
+        L_loop, L_exit, L_rare = ".Lkw_loop_%=", ".Lkw_exit_%=", ".Lkw_rare_%="
+        L_nb1, L_nbd, L_dp, L_nodp, L_fix = ".Lkw_nb1_%=", ".Lkw_nbd_%=", ".Lkw_dp_%=", ".Lkw_nodp_%=", ".Lkw_fix_%="
+        # ================= entry (unscheduled) =================
+        A.cur.schedule = False
+        A.s_nop(4)  # operands may come fresh from a VALU (readfirstlane) : VALU-written SGPR -> SMEM/VMEM
+        A.s_load(16, self.planes, self.args, OFF_PLANES)
+        A.s_load(8, self.dpblk, self.args, OFF_DP)
+        A.s_mov_b32(self.k977, 977)
+        A.v_mov_b32(self.v977, 977)
+        A.s_mov_b64(self.rare, 0)
+        A.s_waitcnt(lgkmcnt=0, regs=[self.planes, self.dpblk])
+        voff8 = A.v("voff8e")
+        A.v_lshrrev_b32(voff8, 1, self.voff)
+        self.load_fe(self.CX, self.voff, "x01", "x23", True)
+        self.load_fe(self.CY, self.voff, "y01", "y23", True)
+        self.load_d(self.CD, voff8)
+        k1 = A.s("k1e")
+        A.s_add_u32(k1, self.k, 1)
+        A.s_cmp("lt_u32", k1, self.G)
+        A.s_cbranch_scc0(L_nb1)
+        A.cur.schedule = False
+        voffn = A.v("voffn_e")
+        A.v_add_u32(voffn, self.stride, self.voff)
+        self.load_fe(self.NB, voffn, "s01", "s23", False)
+        A.s_branch(L_nbd)
+        A.label(L_nb1)
+        A.cur.schedule = False
+        self.set_one(self.NB)
+        A.label(L_nbd)
+        A.cur.schedule = False
+        A.s_waitcnt(vmcnt=0, regs=self.CX + self.CY + [self.CD] + self.NB)
+        # ================= loop =================
+        A.label(L_loop)
+        A.cur.schedule = False
+        # clamped strides for the prefetch: slot(k+1) if it exists else slot(k); slot(k+2) likewise
+        s1, s2, k1, k2 = A.s("s1"), A.s("s2"), A.s("k1"), A.s("k2")
+        A.s_add_u32(k1, self.k, 1)
+        A.s_cmp("lt_u32", k1, self.G)
+        A.s_cselect_b32(s1, self.stride, 0)
+        A.s_add_u32(k2, self.k, 2)
+        A.s_cmp("lt_u32", k2, self.G)
+        A.s_cselect_b32(s2, self.stride, 0)
+        A.s_mov_b64(self.rare, 0)
+        # ---------------- block A: everything up to the exactness check (scheduled as one graph)
+        A.block("A")
+        voffn, voffnn, voffn8 = A.v("voffn"), A.v("voffnn"), A.v("voffn8")
+        A.v_add_u32(voffn, s1, self.voff)
+        A.v_add_u32(voffnn, s2, voffn)
+        A.v_lshrrev_b32(voffn8, 1, voffn)
+        self.load_fe(self.NX, voffn, "x01", "x23", True)
+        self.load_fe(self.NY, voffn, "y01", "y23", True)
+        self.load_d(self.ND, voffn8)
+        self.load_fe(self.NNB, voffnn, "s01", "s23", False)
+        # jump table entry j = x & 31
+        cx, cy = self.limbs(self.CX), self.limbs(self.CY)
+        jidx, laddr = A.v("jidx"), A.v("laddr")
+        A.v_and_b32(jidx, 31, cx[0])
+        A.v_lshl_add_u32(laddr, jidx, 3, self.ldstab)
+        JX, JY = [A.vt("jx0", 4), A.vt("jx1", 4)], [A.vt("jy0", 4), A.vt("jy1", 4)]
+        JD = A.vt("jd", 4)
+        A.ds_read2_b64(JX[0], laddr, 0, 32)
+        A.ds_read2_b64(JX[1], laddr, 64, 96)
+        A.ds_read2_b64(JY[0], laddr, 128, 160)
+        A.ds_read2_b64(JY[1], laddr, 192, 224)
+        A.ds_read_b64(JD.sub(0, 2), laddr, 2048)
+        if not self.dsplit:
+            A.ds_read_b64(JD.sub(2, 2), laddr, 2048 + 256)
+        A.s_waitcnt(lgkmcnt=0, regs=JX + JY + [JD.sub(0, 2)] + ([] if self.dsplit else [JD.sub(2, 2)]))
+        jx, jy = self.limbs(JX), self.limbs(JY)
+        nb = self.limbs(self.NB)
+        # P1: invk = inv * nb ; dx, dy ; P2: inv' = inv * dx
+        IK = kfield.fe_mul(F, self.INV, nb, tag="p1")
+        dx = kfield.fe_sub(F, cx, jx, tag="dx", k977_v=self.v977)
+        dy = kfield.fe_sub(F, cy, jy, tag="dy", k977_v=self.v977)
+        INVn = kfield.fe_mul(F, self.INV, dx, tag="p2")
+        # P3: s = dy * invk ; P4: s^2
+        S = kfield.fe_mul(F, dy, IK, tag="p3")
+        SQ = kfield.fe_mul(F, S, S, tag="p4")
+        # rx = s^2 - jx - cx ; ry = (cx - rx) * s - cy
+        r0 = kfield.fe_sub(F, SQ, jx, tag="ra", k977_v=self.v977)
+        RXq = [A.vt("rx0", 4), A.vt("rx1", 4)]
+        RX = kfield.fe_sub(F, r0, cx, out=self.limbs(RXq), tag="rx", k977_v=self.v977)
+        T = kfield.fe_sub(F, cx, RX, tag="t", k977_v=self.v977)
+        Y0 = kfield.fe_mul(F, T, S, tag="p5")
+        RYq = [A.vt("ry0", 4), A.vt("ry1", 4)]
+        RY = kfield.fe_sub(F, Y0, cy, out=self.limbs(RYq), tag="ry", k977_v=self.v977)
+        # d += jD  (raw 128-bit add, GPUMath.h:119-121)
+        DN = A.vt("dnew", 4)
+        cd = self.CD.regs
+        dc = A.st("dcar", 2)
+        A.v_add_co_u32(DN[0], dc, cd[0], JD[0])
+        A.v_addc_co_u32(DN[1], dc, cd[1], JD[1], dc)
+        if self.dsplit:
+            A.s_or_accum(self.rare, dc)  # carry out of the low word: the high word is updated on the exact path
+        else:
+            A.v_addc_co_u32(DN[2], dc, cd[2], JD[2], dc)
+            A.v_addc_co_u32(DN[3], "vcc", cd[3], JD[3], dc)
+        # prefix product of the next jump's dx: acc' = acc * (rx - J[rx & 31].x)
+        jidx2, laddr2 = A.v("jidx2"), A.v("laddr2")
+        A.v_and_b32(jidx2, 31, RX[0])
+        A.v_lshl_add_u32(laddr2, jidx2, 3, self.ldstab)
+        JX2 = [A.vt("jxn0", 4), A.vt("jxn1", 4)]
+        A.ds_read2_b64(JX2[0], laddr2, 0, 32)
+        A.ds_read2_b64(JX2[1], laddr2, 64, 96)
+        A.s_waitcnt(lgkmcnt=0, regs=JX2)
+        dx2 = kfield.fe_sub(F, RX, self.limbs(JX2), tag="dx2", k977_v=self.v977)
+        ACCq = [A.vt("accn0", 4), A.vt("accn1", 4)]
+        ACCn = kfield.fe_mul(F, self.ACC, dx2, out=self.limbs(ACCq), tag="p6")
+        # distinguished point?  (x.limb3 & dpMask) == 0, GPUCompute.h:96
+        t1, t2 = A.v("dpt1"), A.v("dpt2")
+        A.v_and_b32(t1, self.dp_mask_lo, RX[6])
+        A.v_and_b32(t2, self.dp_mask_hi, RX[7])
+        A.v_or_b32(t1, t1, t2)
+        DPM = A.st("dpm", 2)
+        A.v_cmp_eq_u32(DPM, 0, t1)
+        # everything the stores and the commit need must be complete here
+        A.keep(*INVn, *RX, *RY, *ACCn, *DN.regs[:2 if self.dsplit else 4], DPM)
+        A.s_cmp("lg_u64", self.rare, 0)
+        A.s_cbranch_scc1(L_rare)
+        # ---------------- block B: stores, DP records, commit
+        A.cur.name = "B"
+        voff8 = A.v("voff8")
+        A.v_lshrrev_b32(voff8, 1, self.voff)
+        A.global_store(4, self.voff, RXq[0], self.P["x01"], nt=True)
+        A.global_store(4, self.voff, RXq[1], self.P["x23"], nt=True)
+        A.global_store(4, self.voff, RYq[0], self.P["y01"], nt=True)
+        A.global_store(4, self.voff, RYq[1], self.P["y23"], nt=True)
+        A.global_store(2, voff8, DN.sub(0, 2), self.P["dlo"])
+        if not self.dsplit:
+            A.global_store(2, voff8, DN.sub(2, 2), self.P["dhi"])
+        A.global_store(4, self.voff, ACCq[0], self.P["s01"])
+        A.global_store(4, self.voff, ACCq[1], self.P["s23"])
+        A.s_cmp("lg_u64", DPM, 0)
+        A.s_cbranch_scc0(L_nodp)
+        # ---- cold: wave-compacted DP records (emit_dp of kng_engine.hip; GPUCompute.h:96-105)
+        A.cur.schedule = False
+        A.raw("; cold path")
+        SAVE, ONE, KEEP = A.st("save", 2), A.st("one", 2), A.st("keep", 2)
+        scnt, slead, sbase = A.s("scnt"), A.s("slead"), A.s("sbase")
+        vpos, vcnt, vzero, vbase, vrec = A.v("vpos"), A.v("vcnt"), A.v("vzero"), A.v("vbase"), A.v("vrec")
+        KQ = A.vt("kq", 4)
+        A.s_mov_b64(SAVE, EXEC)
+        if self.dsplit:
+            A.s_mov_exec(DPM)
+            A.global_load(2, DN.sub(2, 2), voff8, self.P["dhi"])
+            A.s_mov_exec(SAVE)
+        A.s_bcnt1_i32_b64(scnt, DPM)
+        A.v_mbcnt_lo(vpos, DPM[0], 0)
+        A.v_mbcnt_hi(vpos, DPM[1], vpos)
+        A.s_ff1_i32_b64(slead, DPM)
+        A.s_lshl_b64(ONE, 1, slead)
+        A.v_mov_b32(vcnt, scnt)
+        A.v_mov_b32(vzero, 0)
+        A.s_mov_exec(ONE)
+        A.global_atomic_add_rtn(vbase, vzero, vcnt, self.dp_count)
+        A.s_waitcnt(vmcnt=0, regs=[vbase] + ([DN.sub(2, 2)] if self.dsplit else []))
+        A.v_readfirstlane_b32(sbase, vbase)
+        A.s_mov_exec(DPM)
+        A.v_add_u32(vpos, sbase, vpos)
+        A.v_cmp_lt_u32(KEEP, vpos, self.max_found)
+        A.v_lshlrev_b32(vrec, 6, vpos)
+        A.v_lshrrev_b32(KQ[0], 4, self.voff)
+        A.v_mov_b32(KQ[1], 0)
+        A.v_mov_b32(KQ[2], 0)
+        A.v_mov_b32(KQ[3], 0)
+        A.s_and_b64(KEEP, KEEP, DPM)
+        A.s_mov_exec(KEEP)
+        A.global_store(4, vrec, RXq[0], self.dp_items)
+        A.global_store(4, vrec, RXq[1], self.dp_items, offset=16)
+        A.global_store(4, vrec, DN, self.dp_items, offset=32)
+        A.global_store(4, vrec, KQ, self.dp_items, offset=48)
+        A.s_mov_exec(SAVE)
+        # ---- commit (the prefetch must have landed: everything issued behind it may still be in flight)
+        A.label(L_nodp)
+        A.cur.schedule = False
+        n_after = 7 if self.dsplit else 8  # stores of this iteration issued behind the prefetch loads (x, y: 4; d: 1 or 2; products: 2)
+        A.s_waitcnt(vmcnt=n_after, regs=self.NX + self.NY + [self.ND.sub(0, 2)] + ([] if self.dsplit else [self.ND.sub(2, 2)]) + self.NNB)
+        A.block("commit")
+        for d, s_ in zip(self.INV, INVn):
+            A.v_mov_b32(d, s_)
+        for d, s_ in zip(self.ACC, ACCn):
+            A.v_mov_b32(d, s_)
+        for dq, sq in ((self.CX, self.NX), (self.CY, self.NY), (self.NB, self.NNB)):
+            for d, s_ in zip(self.limbs(dq), self.limbs(sq)):
+                A.v_mov_b32(d, s_)
+        for i in range(2 if self.dsplit else 4):
+            A.v_mov_b32(self.CD[i], self.ND[i])
+        A.v_mov_b32(self.voff, voffn)
+        A.block("next", schedule=False)
+        k1b = A.s("k1b")
+        A.s_add_u32(self.k, self.k, 1)
+        A.s_add_u32(k1b, self.k, 1)
+        A.s_cmp("lt_u32", k1b, self.G)
+        A.s_cbranch_scc1(L_fix)
+        A.cur.schedule = False
+        self.set_one(self.NB)  # the last kangaroo of the pass has no neighbour product: nb = 1 (walk_body: invk = inv)
+        A.label(L_fix)
+        A.cur.schedule = False
+        A.s_cmp("lt_u32", self.k, self.G)
+        A.s_cbranch_scc1(L_loop)
+        # ================= exits =================
+        A.label(L_rare)
+        A.cur.schedule = False
+        A.raw("; cold path")
+        A.label(L_exit)
+        A.cur.schedule = False
+        A.s_waitcnt(vmcnt=0, lgkmcnt=0)
+        A.s_nop(1)
+        return self
+
+
+VPOOL = list(range(64, 256))
+SPOOL = list(range(36, 100))
+
+
+def generate(dsplit, vpool=VPOOL, spool=SPOOL):
+    lp = Loop(dsplit).build()
+    kasm.schedule(lp.A)
+    used = kasm.allocate(lp.A, vpool, spool)
+    probs = kasm.verify(lp.A)
+    return lp, used, probs
+
+
+def c_string(lines):
+    out = []
+    for t in lines:
+        t = t.split("\t;")[0].rstrip()
+        out.append('        "' + t.replace("\t", " ").strip() + '\\n"')
+    return "\n".join(out)
+
+
+def main():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    parts = []
+    info = {}
+    for dsplit in (True, False):
+        lp, used, probs = generate(dsplit)
+        if probs:
+            raise SystemExit("\n".join(probs))
+        text = kasm.listing(lp.A, comments=False)
+        st = kasm.stats(lp.A, blocks={"A", "B", "commit", "next"})
+        info[dsplit] = (st, used)
+        clob = [f'"v{n}"' for n in sorted(used["v"])] + [f'"s{n}"' for n in sorted(used["s"])] + ['"vcc"', '"scc"', '"memory"']
+        name = "KNG_WALK_ASM_TEXT_DSPLIT" if dsplit else "KNG_WALK_ASM_TEXT_FULL"
+        parts.append(f"// distance layout: {'low word streams (DSPLIT)' if dsplit else 'both words stream'}; hot blocks: {st}\n"
+                     f"#define {name} \\\n" + " \\\n".join(c_string(text).split("\n")) + "\n"
+                     f"#define {name.replace('TEXT', 'CLOBBERS')} {', '.join(clob)}\n")
+    hdr = '''// GENERATED by tools/gen_walk_asm.py (tools/kasm.py scheduler + allocator, tools/kfield.py arithmetic) -- do not edit.
+// The per-kangaroo loop of the walk kernel as one scheduled asm statement; see the generator for the protocol.
+// Replaces the loop body of ComputeKangaroos (GPU/GPUCompute.h:52-105 of the reference).
+#pragma once
+
+''' + "\n".join(parts) + '''
+// operands: %0-%7 inv, %8-%15 acc, %16 k, %17 voff (all read-write); %18 args, %19 stride, %20 G, %21 lds table address
+#define KNG_WALK_ASM_LOOP(TEXT, CLOBBERS, inv, acc, k, voff, args, stride, G, ldstab)                                         \\
+    asm volatile(TEXT                                                                                                          \\
+                 : "+v"(inv[0]), "+v"(inv[1]), "+v"(inv[2]), "+v"(inv[3]), "+v"(inv[4]), "+v"(inv[5]), "+v"(inv[6]), "+v"(inv[7]), \\
+                   "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), \\
+                   "+s"(k), "+v"(voff)                                                                                         \\
+                 : "s"(args), "s"(stride), "s"(G), "s"(ldstab)                                                                 \\
+                 : CLOBBERS)
+'''
+    path = os.path.join(root, "kangaroo_amd", "csrc", "kng_walk_asm.h")
+    open(path, "w").write(hdr)
+    for ds, (st, used) in info.items():
+        print(f"dsplit={ds}: hot blocks {st}; {len(used['v'])} VGPRs (max v{max(used['v'])}), {len(used['s'])} SGPRs")
+    print("wrote", path)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""kfield -- secp256k1 field arithmetic on 32-bit limbs, written against tools/kasm.py's builder.
+
+Same integers as kangaroo_amd/csrc/kng_field.h (which restates GPU/GPUMath.h:476-516, :810-907 of the reference):
+  mul  : 256x256 -> 512 Comba (product scanning), v_mad_u64_u32 with the carry in an SGPR pair, one v_addc per MAD
+  fold : S = lo + hi*(2^32+977) in ONE carry chain (E/O trick of kng_field.h fe_fold32), T = S >> 256 folded again,
+         last carry dropped.  Conditions under which the short form is not exact are ORed into `rare`.
+  sub  : a - b, + p on borrow (exact except for the borrow leaving the low 64 bits, which is ORed into `rare`)
+Everything is emitted in dependency order only; kasm.schedule() interleaves the chains so that the 2 wait states
+between a VALU carry write and its VALU reader are filled by independent work instead of s_nop.
+
+Register discipline of the product (one v_mov per column): even column 2m accumulates in the pair
+PW[m] whose halves end up as (w[2m], w[2m+1]) -- the aligned pairs the fold's 64-bit addends need; odd columns use a
+temporary pair.  gfx90a+ wants 64-bit VGPR operands even-aligned, so the high half of one column's accumulator cannot
+serve as the low half of the next one's: that costs the move.
+"""
+from __future__ import annotations
+
+from kasm import Asm
+
+DUMMY = "vcc"  # carry-outs nobody reads go to vcc, untracked: scheduled code never keeps a live value in vcc
+
+P = (1 << 256) - (1 << 32) - 977
+K = (1 << 32) + 977
+
+
+class Field:
+    def __init__(self, A: Asm, k977_s, rare):
+        """k977_s: SGPR holding 977; rare: SGPR pair that collects "short form not exact" lane masks"""
+        self.A, self.k977, self.rare = A, k977_s, rare
+        self.n = 0
+
+    def uid(self, stem):
+        self.n += 1
+        return f"{stem}{self.n}"
+
+
+def comba(F: Field, a, b, tag="m"):
+    """a, b: 8 Regs each.  Returns PW: 8 pairs, PW[m] = (w[2m], w[2m+1]) (module docstring: register discipline)."""
+    A = F.A
+    PW = [A.vt(F.uid(f"{tag}pw"), 2) for _ in range(8)]
+    # accumulator of every column, created up front: even columns in PW, odd ones in temporaries
+    accs = [PW[k // 2] if k % 2 == 0 else A.vt(F.uid(f"{tag}t"), 2) for k in range(15)]
+    for k in range(15):
+        acc = accs[k]
+        terms = [(i, k - i) for i in range(max(0, k - 7), min(7, k) + 1)]
+        if k == 0:
+            addend = 0
+        else:
+            prev = accs[k - 1]
+            A.v_mov_b32(acc.lo, prev.hi, comment=f"col {k} <- carry word of col {k - 1}")
+            if k % 2 == 0:
+                # prev is an odd column's temporary: its low word is w[k-1]; park it beside w[k-2]
+                A.v_mov_b32(PW[(k - 1) // 2].hi, prev.lo, comment=f"pack w{k - 1}")
+            if k == 1:
+                A.v_mov_b32(acc.hi, 0)  # column 0 cannot carry
+            addend = acc
+        can_overflow = 0 < k < 14
+        carries = []
+        for n_, (i, j) in enumerate(terms):
+            c = A.st(F.uid("c"), 2) if can_overflow else DUMMY
+            A.v_mad_u64_u32(acc, c, a[i], b[j], addend if n_ == 0 else acc, comment=f"a{i}*b{j}")
+            if can_overflow:
+                carries.append(c)
+        if carries:
+            nhi = accs[k + 1].hi
+            for n_, c in enumerate(carries):
+                A.v_addc_co_u32(nhi, DUMMY, 0, 0 if n_ == 0 else nhi, c)
+    # column 13's low word (w13) still sits in its temporary; column 14 is PW[7] = (w14, w15)
+    # (the k == 14 iteration above packed w13 into PW[6].hi)
+    return PW
+
+
+def fold(F: Field, PW, out=None, tag="f"):
+    """PW: 8 pairs (w[2m], w[2m+1]).  out: optional list of 8 Regs to receive the result (out[0], out[1] must be an
+    even-aligned pair).  Returns the 8 result registers."""
+    A = F.A
+    e = [A.vt(F.uid(f"{tag}e"), 2) for _ in range(4)]
+    o = [A.vt(F.uid(f"{tag}o"), 2) for _ in range(4)]
+    flags = []
+    for j in range(4):
+        ce, co = A.st(F.uid("ce"), 2), A.st(F.uid("co"), 2)
+        A.v_mad_u64_u32(e[j], ce, PW[4 + j].lo, F.k977, PW[j], comment=f"E{j} = w{8 + 2 * j}*977 + (w{2 * j},w{2 * j + 1})")
+        A.v_mad_u64_u32(o[j], co, PW[4 + j].hi, F.k977, PW[4 + j], comment=f"O{j} = w{9 + 2 * j}*977 + (w{8 + 2 * j},w{9 + 2 * j})")
+        flags += [ce, co]
+    if out is None:
+        r01 = A.vt(F.uid(f"{tag}r"), 2)
+        out = [r01.lo, r01.hi] + [A.v(F.uid(f"{tag}r")) for _ in range(6)]
+    elif out[0].tup is not None and out[1].tup is out[0].tup and out[0].idx % 2 == 0 and out[1].idx == out[0].idx + 1:
+        r01 = out[0].tup.sub(out[0].idx, 2) if len(out[0].tup) > 2 else out[0].tup
+    else:
+        r01 = A.vt(F.uid(f"{tag}r"), 2)  # out[0], out[1] are no aligned pair (compiler-allocated operands): one move
+    # S = E + O<<32 : one chain.  s0 = e0.lo, s1 written over e0.hi so that (s0, s1) stays an aligned pair
+    C = A.st(F.uid("fc"), 2)
+    A.v_add_co_u32(e[0].hi, C, e[0].hi, o[0].lo, comment="s1")
+    s = [e[0].lo, e[0].hi, None, None, None, None, None, None, None]
+    s2 = A.v(F.uid(f"{tag}s2"))
+    A.v_addc_co_u32(s2, C, e[1].lo, o[0].hi, C, comment="s2")
+    s[2] = s2
+    srcs = {3: (e[1].hi, o[1].lo), 4: (e[2].lo, o[1].hi), 5: (e[2].hi, o[2].lo), 6: (e[3].lo, o[2].hi), 7: (e[3].hi, o[3].lo)}
+    for i in range(3, 8):
+        A.v_addc_co_u32(out[i], C, srcs[i][0], srcs[i][1], C, comment=f"s{i}")
+    s8 = A.v(F.uid(f"{tag}s8"))
+    A.v_addc_co_u32(s8, C, o[3].hi, 0, C, comment="s8; carry-out = bit 32 of T")
+    flags.append(C)  # top: T >= 2^32 (hi7 within 978 of 2^32)
+    # second fold: T*K = s8*977 + (s8 << 32)
+    c1 = A.st(F.uid("c1"), 2)
+    A.v_mad_u64_u32(r01, c1, s8, F.k977, e[0], comment="(r0,r1') = s8*977 + (s0,s1)")
+    flags.append(c1)
+    C2 = A.st(F.uid("fd"), 2)
+    A.v_add_co_u32(out[1], C2, r01[1], s8, comment="r1")
+    if out[0] is not r01[0]:
+        A.v_mov_b32(out[0], r01[0], comment="r0")
+    A.v_addc_co_u32(out[2], C2, s2, 0, C2, comment="r2; carry-out leaves limb 2 only when it was all ones")
+    flags.append(C2)
+    for m in flags:
+        A.s_or_accum(F.rare, m)
+    return out
+
+
+def fe_mul(F: Field, a, b, out=None, tag="m"):
+    return fold(F, comba(F, a, b, tag), out, tag)
+
+
+def fe_sub(F: Field, x, y, out=None, tag="s", k977_v=None):
+    """r = x - y, + p on borrow.  k977_v: VGPR holding 977 (v_cndmask cannot take two SGPRs)."""
+    A = F.A
+    if out is None:
+        out = [A.v(F.uid(f"{tag}r")) for _ in range(8)]
+    B = A.st(F.uid("sb"), 2)
+    t = [A.v(F.uid(f"{tag}t")) for _ in range(2)]
+    A.v_sub_co_u32(t[0], B, x[0], y[0])
+    A.v_subb_co_u32(t[1], B, x[1], y[1], B)
+    for i in range(2, 8):
+        A.v_subb_co_u32(out[i], B, x[i], y[i], B)
+    # borrow: subtract 2^256 - p = 2^32 + 977
+    q0, q1 = A.v(F.uid(f"{tag}q")), A.v(F.uid(f"{tag}q"))
+    A.v_cndmask_b32(q0, 0, k977_v, B)
+    A.v_cndmask_b32(q1, 0, 1, B)
+    D = A.st(F.uid("sd"), 2)
+    A.v_sub_co_u32(out[0], D, t[0], q0)
+    A.v_subb_co_u32(out[1], D, t[1], q1, D)
+    A.s_or_accum(F.rare, D)  # the borrow leaves the low 64 bits once in 2^32: exact path elsewhere
+    return out
+
+
+# ---- plain-integer restatements (what the emulated code must reproduce, and when it may set `rare`)
+
+
+def ref_mul(a, b):
+    """GPUMath.h:810-858 / IntMod.cpp:873-950: fold twice, drop the last carry, no comparison with p"""
+    w = a * b
+    lo, hi = w & ((1 << 256) - 1), w >> 256
+    s = lo + hi * K
+    t = s >> 256
+    return ((s & ((1 << 256) - 1)) + t * K) & ((1 << 256) - 1)
+
+
+def ref_sub(a, b):
+    r = a - b
+    if r < 0:
+        r += P
+    return r & ((1 << 256) - 1)
+
+
+def limbs(x, n=8):
+    return [(x >> (32 * i)) & 0xFFFFFFFF for i in range(n)]
+
+
+def unlimbs(v):
+    return sum(int(x) << (32 * i) for i, x in enumerate(v))
