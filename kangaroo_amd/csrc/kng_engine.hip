@@ -32,6 +32,7 @@
 #include "../../include/kangaroo_hip.h"
 #include "kng_field.h"
 #include "kng_modinv.h"
+#include "kng_walk_asm.h"
 
 using namespace kng;
 
@@ -59,7 +60,16 @@ struct WalkArgs {
     uint32_t group; // nominal G (exact when lanes divides the herd)
     uint64_t n_kang; // N: lane t walks kangaroos t, t+L, ... < N, i.e. ceil((N-t)/L) of them (uniform per wave: L is a multiple of 64)
     uint32_t nsteps;
+    uint64_t asm_args; // device address of this launch's WalkAsmArgs (the scheduled loop reads its constants with s_load)
 };
+
+// what the generated loop (kng_walk_asm.h, tools/gen_walk_asm.py: OFF_PLANES / OFF_DP) loads: plane bases, then the DP block
+struct WalkAsmArgs {
+    uint64_t x01, x23, y01, y23, dlo, dhi, s01, s23;
+    uint64_t dp_mask, dp_count, dp_items;
+    uint32_t max_found, pad;
+};
+static_assert(sizeof(WalkAsmArgs) == 96 && offsetof(WalkAsmArgs, dp_mask) == 0x40, "layout the generated loop expects");
 
 #define JT_JX 0
 #define JT_JY (4 * 32)
@@ -167,6 +177,71 @@ KNG_DEV void emit_dp(bool is_dp, const fe &x, const v16 &d, uint64_t kidx, const
     }
 }
 
+// One kangaroo's jump given its loaded state: P += J[x & 31] (GPUCompute.h:67-94), d += jD, store, DP test and record
+// (GPUCompute.h:96-105), prefix product of the next jump's dx.  Shared by the compiler-scheduled loop (which prefetches
+// cx/cy/cd/nb one kangaroo ahead) and by the exact path behind the scheduled asm loop (walk_one).
+template <bool DSPLIT>
+KNG_DEV void walk_core(const WalkArgs &a, const uint64_t *tab, uint64_t *dlo, uint64_t *dhi, size_t idx, const fe &cx, const fe &cy,
+                       v16 cd, const fe &nb, bool have_nb, bool first, bool last, fe &inv, fe &acc) {
+    const uint32_t j = (uint32_t)cx.v[0] & (KNG_NB_JUMP - 1);
+    const fe jx = lds_fe(tab, JT_JX, j);
+    const fe jy = lds_fe(tab, JT_JY, j);
+    const fe dx = fe_sub(cx, jx);
+    fe invk;
+    if (have_nb) {
+        invk = fe_mul(inv, nb); // 1/dx      (GPUMath.h:1182-1186)
+        inv = fe_mul(inv, dx);  // 1/(product of the remaining dx)
+    } else {
+        invk = inv;
+    }
+    const fe dy = fe_sub(cy, jy);
+    const fe s = fe_mul(dy, invk);
+    const fe p2 = fe_sqr(s);
+    const fe rx = fe_sub(fe_sub(p2, jx), cx);
+    const fe ry = fe_sub(fe_mul(fe_sub(cx, rx), s), cy);
+    // d += jD[j]: raw 128-bit add (GPUMath.h:119-121)
+    bool hi_known = !DSPLIT;
+    {
+        const uint64_t jd0 = tab[JT_JD + j];
+        unsigned long long c = 0;
+        cd.x = __builtin_addcll(cd.x, jd0, 0, &c);
+        if (DSPLIT) {
+            if (__builtin_expect(c != 0, 0)) {
+                KNG_RARE_PATH();
+                cd.y = dhi[idx] + 1;
+                dhi[idx] = cd.y;
+                hi_known = true;
+            }
+        } else {
+            cd.y = cd.y + tab[JT_JD + 32 + j] + c;
+        }
+    }
+    st_fe(a.x01, a.x23, idx, rx);
+    st_fe(a.y01, a.y23, idx, ry);
+    st_stream64(dlo + idx, cd.x);
+    if (!DSPLIT) st_stream64(dhi + idx, cd.y);
+
+    // ---- distinguished point? (GPUCompute.h:96-105) ----
+    {
+        const bool is_dp = (rx.v[3] & a.dp_mask) == 0;
+        if (DSPLIT && is_dp && !hi_known) {
+            cd.y = dhi[idx];
+            // consume the value inside the branch: a load left pending at the join would make hipcc
+            // drain every outstanding memory operation (vmcnt(0)) at the top of the next iteration
+            asm volatile("" ::"v"(cd.y));
+        }
+        emit_dp(is_dp, rx, cd, (uint64_t)idx, a);
+    }
+
+    // ---- prefix product of the NEXT jump's dx, in this pass's order ----
+    if (!last) {
+        const uint32_t j2 = (uint32_t)rx.v[0] & (KNG_NB_JUMP - 1);
+        const fe dx2 = fe_sub(rx, lds_fe(tab, JT_JX, j2));
+        acc = first ? dx2 : fe_mul(acc, dx2);
+        st_prod(a.s01, a.s23, idx, acc);
+    }
+}
+
 // The hot kernel.  Replaces comp_kangaroos/ComputeKangaroos (GPUEngine.cu:35-40, GPUCompute.h:22-117).
 //
 // SHARE = 2 (512-thread blocks, option "share"): the two waves that occupy one SIMD (waves w, w+4
@@ -180,7 +255,13 @@ KNG_DEV void emit_dp(bool is_dp, const fe &x, const v16 &d, uint64_t kidx, const
 // with probability jD/2^64 (2^-23 per jump at an 80-bit range); the high word is read-modified-written on
 // that rare path and fetched when a distinguished point is emitted.  Saves 16 of 224 B/jump.  The host
 // enables it when every jump distance is below 2^50 (kng_set_params); results are identical.
-template <int SHARE, bool DSPLIT>
+//
+// ASM = true (option "asm", the default): the per-kangaroo loop of every step but the last runs as ONE scheduled asm
+// statement (kng_walk_asm.h, generated by tools/gen_walk_asm.py) instead of the compiler-scheduled loop below -- same
+// data flow, same results, no hazard nops and a third of the register moves.  Its short arithmetic forms flag the lanes
+// for which they are not exact; the statement then returns BEFORE storing anything of that iteration and the wave runs
+// it through walk_core (exact on every input), then re-enters the statement behind it.
+template <int SHARE, bool DSPLIT, bool ASM>
 KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
     uint64_t *const dlo = reinterpret_cast<uint64_t *>(a.d), *const dhi = dlo + a.n_kang;
     const size_t L = a.lanes;
@@ -244,6 +325,40 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
         // slot(k): kangaroo processed k-th in this pass
         auto slot = [&](uint32_t k) -> size_t { return (size_t)(backward ? (G - 1 - k) : k) * L + t; };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (ASM && !last) {
+            // G is wave-uniform (L is a multiple of 64); the statement keeps its loop counter in an SGPR
+            const uint32_t Gs = __builtin_amdgcn_readfirstlane(G);
+            // (readfirstlane: the "s" operands must be provably wave-uniform for the compiler)
+            const uint32_t ldstab = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tab); // LDS byte address = low half of the flat address
+            const int32_t stride = __builtin_amdgcn_readfirstlane(backward ? -(int32_t)(L * 16) : (int32_t)(L * 16));
+            const uint64_t aargs = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(a.asm_args >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)a.asm_args);
+            uint32_t iv[8], ac[8] = {1, 0, 0, 0, 0, 0, 0, 0}; // acc' = acc * dx2 with acc = 1 for the first kangaroo (exact)
+            fe_to32(iv, inv);
+            uint32_t k = 0;
+            while (true) {
+                uint32_t voff = (uint32_t)slot(k) * 16u;
+                uint32_t ks = __builtin_amdgcn_readfirstlane(k);
+                if (DSPLIT) KNG_WALK_ASM_LOOP(KNG_WALK_ASM_TEXT_DSPLIT, KNG_WALK_ASM_CLOBBERS_DSPLIT, iv, ac, ks, voff, aargs, stride, Gs, ldstab);
+                else KNG_WALK_ASM_LOOP(KNG_WALK_ASM_TEXT_FULL, KNG_WALK_ASM_CLOBBERS_FULL, iv, ac, ks, voff, aargs, stride, Gs, ldstab);
+                k = ks;
+                if (k >= Gs) break;
+                // exact path: some lane of this wave needs the general arithmetic for kangaroo k; nothing of it was stored
+                KNG_RARE_PATH();
+                fe xi = fe_from32(iv), xa = fe_from32(ac);
+                const size_t idx = slot(k);
+                const bool have_nb = k + 1 < G;
+                const fe nb = have_nb ? ld_prod(a.s01, a.s23, slot(k + 1)) : fe_one();
+                const v16 cd = DSPLIT ? make_ulonglong2(ld_stream64(dlo + idx), 0) : ld_d(a.d, a.n_kang, idx);
+                walk_core<DSPLIT>(a, tab, dlo, dhi, idx, ld_fe(a.x01, a.x23, idx), ld_fe(a.y01, a.y23, idx), cd, nb, have_nb, k == 0, false, xi, xa);
+                fe_to32(iv, xi);
+                fe_to32(ac, xa);
+                if (++k >= Gs) break;
+            }
+            acc = fe_from32(ac);
+            continue;
+        }
+#endif
         size_t idx = slot(0);
         fe cx = ld_fe(a.x01, a.x23, idx);
         fe cy = ld_fe(a.y01, a.y23, idx);
@@ -262,65 +377,7 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
                 nd = DSPLIT ? make_ulonglong2(ld_stream64(dlo + nidx), 0) : ld_d(a.d, a.n_kang, nidx);
             }
             if (k + 2 < G) nnb = ld_prod(a.s01, a.s23, slot(k + 2));
-
-            // ---- this kangaroo: P += J[x & 31]   (GPUCompute.h:67-94) ----
-            const uint32_t j = (uint32_t)cx.v[0] & (KNG_NB_JUMP - 1);
-            const fe jx = lds_fe(tab, JT_JX, j);
-            const fe jy = lds_fe(tab, JT_JY, j);
-            const fe dx = fe_sub(cx, jx);
-            fe invk;
-            if (k + 1 < G) {
-                invk = fe_mul(inv, nb); // 1/dx      (GPUMath.h:1182-1186)
-                inv = fe_mul(inv, dx);  // 1/(product of the remaining dx)
-            } else {
-                invk = inv;
-            }
-            const fe dy = fe_sub(cy, jy);
-            const fe s = fe_mul(dy, invk);
-            const fe p2 = fe_sqr(s);
-            const fe rx = fe_sub(fe_sub(p2, jx), cx);
-            const fe ry = fe_sub(fe_mul(fe_sub(cx, rx), s), cy);
-            // d += jD[j]: raw 128-bit add (GPUMath.h:119-121)
-            bool hi_known = !DSPLIT;
-            {
-                const uint64_t jd0 = tab[JT_JD + j];
-                unsigned long long c = 0;
-                cd.x = __builtin_addcll(cd.x, jd0, 0, &c);
-                if (DSPLIT) {
-                    if (__builtin_expect(c != 0, 0)) {
-                        KNG_RARE_PATH();
-                        cd.y = dhi[idx] + 1;
-                        dhi[idx] = cd.y;
-                        hi_known = true;
-                    }
-                } else {
-                    cd.y = cd.y + tab[JT_JD + 32 + j] + c;
-                }
-            }
-            st_fe(a.x01, a.x23, idx, rx);
-            st_fe(a.y01, a.y23, idx, ry);
-            st_stream64(dlo + idx, cd.x);
-            if (!DSPLIT) st_stream64(dhi + idx, cd.y);
-
-            // ---- distinguished point? (GPUCompute.h:96-105) ----
-            {
-                const bool is_dp = (rx.v[3] & a.dp_mask) == 0;
-                if (DSPLIT && is_dp && !hi_known) {
-                    cd.y = dhi[idx];
-                    // consume the value inside the branch: a load left pending at the join would make hipcc
-                    // drain every outstanding memory operation (vmcnt(0)) at the top of the next iteration
-                    asm volatile("" ::"v"(cd.y));
-                }
-                emit_dp(is_dp, rx, cd, (uint64_t)idx, a);
-            }
-
-            // ---- prefix product of the NEXT jump's dx, in this pass's order ----
-            if (!last) {
-                const uint32_t j2 = (uint32_t)rx.v[0] & (KNG_NB_JUMP - 1);
-                const fe dx2 = fe_sub(rx, lds_fe(tab, JT_JX, j2));
-                acc = k ? fe_mul(acc, dx2) : dx2;
-                st_prod(a.s01, a.s23, idx, acc);
-            }
+            walk_core<DSPLIT>(a, tab, dlo, dhi, idx, cx, cy, cd, nb, k + 1 < G, k == 0, last, inv, acc);
             cx = nx;
             cy = ny;
             cd = nd;
@@ -333,13 +390,13 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
 // SHARE = 1: 256-thread blocks, every wave inverts for itself (small herds, option "share").  SHARE = 2: 512-thread
 // blocks, waves w and w+4 share one inversion.  (Round 2 also carried SHARE = 3 and two non-template twins of <1,.>;
 // share 3 lost at every herd size, profiles/r02_group_share_sweep.txt, and was dropped in round 3.)
-template <int SHARE, bool DSPLIT>
+template <int SHARE, bool DSPLIT, bool ASM>
 __global__ void __launch_bounds__(256 * SHARE) kng_walk_share_kernel(const WalkArgs a) {
     __shared__ uint64_t tab[JT_WORDS];
     __shared__ v16 xch[SHARE > 1 ? 512 * (SHARE - 1) : 1];
     for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
     __syncthreads();
-    walk_body<SHARE, DSPLIT>(a, tab, xch);
+    walk_body<SHARE, DSPLIT, ASM>(a, tab, xch);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -530,7 +587,9 @@ struct kng_engine {
     int dsplit = -1;       // distance plane: -1 = low-word streaming when every jump distance < 2^50, 0 = never, 1 = whenever the table allows (high words all zero)
     bool dsplit_on = false; // decided by kng_set_params / the option
     uint64_t jd_max = 0;    // largest low word of the jump distances, UINT64_MAX when a high word is set
-    int share = 2;         // waves per SIMD (w, w+4, ..) of one 256*share-thread block that share one inversion per jump (policy 32)
+    int share = 2;         // waves per SIMD (w, w+4) of one 256*share-thread block that share one inversion per jump
+    int use_asm = 1;       // the scheduled asm loop (kng_walk_asm.h) instead of the compiler-scheduled one; herds beyond 2^28 cannot
+    WalkAsmArgs *asm_args = nullptr; // device: one block per DP buffer
     v16 *planes = nullptr; // 7 planes of n v16
     uint64_t *jtab = nullptr;
     uint32_t *dp_count[2] = {nullptr, nullptr};
@@ -647,6 +706,9 @@ int kng_create(int dev, int grid_x, int grid_y, uint32_t max_found, kng_engine *
     if ((e = hipMalloc((void **)&h->planes, state_bytes)) != hipSuccess)
         return bail(fail(KNG_E_ALLOC, "herd state (%zu bytes): %s", state_bytes, hipGetErrorString(e)));
     if ((e = hipMalloc((void **)&h->jtab, JT_WORDS * 8)) != hipSuccess) return bail(fail(KNG_E_ALLOC, "jump table: %s", hipGetErrorString(e)));
+    if ((e = hipMalloc((void **)&h->asm_args, 2 * sizeof(WalkAsmArgs))) != hipSuccess) return bail(fail(KNG_E_ALLOC, "loop arguments: %s", hipGetErrorString(e)));
+    // the scheduled loop addresses a plane as base + 32-bit byte offset and a DP record as base + 32-bit offset
+    if (h->n > (1ull << 28) || max_found > (1u << 26)) h->use_asm = 0;
     for (int s = 0; s < 2; s++) {
         if ((e = hipMalloc((void **)&h->dp_count[s], 64)) != hipSuccess) return bail(fail(KNG_E_ALLOC, "dp counter: %s", hipGetErrorString(e)));
         if ((e = hipMalloc((void **)&h->dp_items[s], (size_t)max_found * sizeof(DpRecord))) != hipSuccess)
@@ -680,6 +742,7 @@ void kng_destroy(kng_engine *h) {
     if (h->copy) (void)hipStreamSynchronize(h->copy);
     if (h->planes) (void)hipFree(h->planes);
     if (h->jtab) (void)hipFree(h->jtab);
+    if (h->asm_args) (void)hipFree(h->asm_args);
     for (int s = 0; s < 2; s++) {
         if (h->dp_count[s]) (void)hipFree(h->dp_count[s]);
         if (h->dp_items[s]) (void)hipFree(h->dp_items[s]);
@@ -724,6 +787,10 @@ int kng_set_option(kng_engine *h, const char *key, int64_t value) {
     } else if (k == "share") {
         if (value < 1 || value > 2) return fail(KNG_E_ARG, "share must be 1 or 2");
         h->share = (int)value;
+    } else if (k == "asm") {
+        if (value < 0 || value > 1) return fail(KNG_E_ARG, "asm must be 0 or 1");
+        if (value && (h->n > (1ull << 28) || h->max_found > (1u << 26))) return fail(KNG_E_ARG, "the scheduled loop addresses at most 2^28 kangaroos and 2^26 DP records");
+        h->use_asm = (int)value;
     } else {
         return fail(KNG_E_ARG, "unknown option '%s'", key);
     }
@@ -738,6 +805,7 @@ int kng_get_option(const kng_engine *h, const char *key, int64_t *value) {
     else if (k == "steps") *value = h->nsteps;
     else if (k == "lanes") *value = h->lanes;
     else if (k == "share") *value = h->share;
+    else if (k == "asm") *value = h->use_asm;
     else if (k == "dsplit") *value = h->dsplit_on ? 1 : 0;
     else if (k == "cu_count") *value = h->cu_count;
     else if (k == "waves_per_cu") *value = h->cu_count ? (int64_t)((h->lanes / 64 + h->cu_count - 1) / h->cu_count) : 0;
@@ -764,8 +832,18 @@ int kng_set_params(kng_engine *h, uint64_t dp_mask, const uint64_t *jd, const ui
         else if (h->jd_max != UINT64_MAX && jd[2 * j] > h->jd_max) h->jd_max = jd[2 * j];
     }
     decide_dsplit(h);
+    // constants of the scheduled loop, one block per DP buffer
+    WalkAsmArgs aa[2];
+    for (int s = 0; s < 2; s++) {
+        aa[s].x01 = (uint64_t)plane(h, 0); aa[s].x23 = (uint64_t)plane(h, 1); aa[s].y01 = (uint64_t)plane(h, 2); aa[s].y23 = (uint64_t)plane(h, 3);
+        aa[s].dlo = (uint64_t)dplane(h, 0); aa[s].dhi = (uint64_t)dplane(h, 1);
+        aa[s].s01 = (uint64_t)plane(h, 5); aa[s].s23 = (uint64_t)plane(h, 6);
+        aa[s].dp_mask = dp_mask; aa[s].dp_count = (uint64_t)h->dp_count[s]; aa[s].dp_items = (uint64_t)h->dp_items[s];
+        aa[s].max_found = h->max_found; aa[s].pad = 0;
+    }
     // stream-ordered after any in-flight launch
     HIP_TRY(hipMemcpyAsync(h->jtab, tab, sizeof tab, hipMemcpyHostToDevice, h->walk));
+    HIP_TRY(hipMemcpyAsync(h->asm_args, aa, sizeof aa, hipMemcpyHostToDevice, h->walk));
     HIP_TRY(hipStreamSynchronize(h->walk));
     h->dp_mask = dp_mask;
     h->have_params = true;
@@ -908,17 +986,21 @@ int kng_launch(kng_engine *h) {
     a.group = h->group;
     a.n_kang = h->n;
     a.nsteps = h->nsteps;
+    a.asm_args = (uint64_t)(h->asm_args + s);
     HIP_TRY(hipMemsetAsync(h->dp_count[s], 0, 4, h->walk)); // GPUEngine.cu:543
     HIP_TRY(hipEventRecord(h->ev_start[s], h->walk));
     const uint32_t blocks = (h->lanes + h->block - 1) / h->block;
     const bool ds = h->dsplit_on;
+    const dim3 grid2((h->lanes + 511) / 512), grid1(blocks);
+#define KNG_LAUNCH(SH, DS, AS, GRID, BLOCK) hipLaunchKernelGGL((kng_walk_share_kernel<SH, DS, AS>), GRID, dim3(BLOCK), 0, h->walk, a)
     if (h->share == 2) {
-        if (ds) hipLaunchKernelGGL((kng_walk_share_kernel<2, true>), dim3((h->lanes + 511) / 512), dim3(512), 0, h->walk, a);
-        else hipLaunchKernelGGL((kng_walk_share_kernel<2, false>), dim3((h->lanes + 511) / 512), dim3(512), 0, h->walk, a);
+        if (h->use_asm) { if (ds) KNG_LAUNCH(2, true, true, grid2, 512); else KNG_LAUNCH(2, false, true, grid2, 512); }
+        else { if (ds) KNG_LAUNCH(2, true, false, grid2, 512); else KNG_LAUNCH(2, false, false, grid2, 512); }
     } else {
-        if (ds) hipLaunchKernelGGL((kng_walk_share_kernel<1, true>), dim3(blocks), dim3(h->block), 0, h->walk, a);
-        else hipLaunchKernelGGL((kng_walk_share_kernel<1, false>), dim3(blocks), dim3(h->block), 0, h->walk, a);
+        if (h->use_asm) { if (ds) KNG_LAUNCH(1, true, true, grid1, h->block); else KNG_LAUNCH(1, false, true, grid1, h->block); }
+        else { if (ds) KNG_LAUNCH(1, true, false, grid1, h->block); else KNG_LAUNCH(1, false, false, grid1, h->block); }
     }
+#undef KNG_LAUNCH
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev_stop[s], h->walk));
     HIP_TRY(hipMemcpyAsync(h->h_count[s], h->dp_count[s], 4, hipMemcpyDeviceToHost, h->walk));

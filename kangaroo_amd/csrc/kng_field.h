@@ -210,6 +210,11 @@ KNG_DEV void fe_to32(uint32_t r[8], const fe &a) {
     }
 }
 
+KNG_DEV fe fe_from32(const uint32_t r[8]) {
+    return fe{{(uint64_t)r[0] | ((uint64_t)r[1] << 32), (uint64_t)r[2] | ((uint64_t)r[3] << 32),
+               (uint64_t)r[4] | ((uint64_t)r[5] << 32), (uint64_t)r[6] | ((uint64_t)r[7] << 32)}};
+}
+
 // Same integer as GPUMath.h:810-858 on every input: the single-chain fold first; when one of its "this cannot be
 // right" conditions holds in some lane (about once in 2^13 wave-products on random operands) the wave folds again
 // with every carry rippled.

@@ -330,20 +330,22 @@ def test_full_size_herd_properties(kng, orc):
     assert np.array_equal(gx_[sub], ox) and np.array_equal(gy_[sub], oy) and np.array_equal(gd_[sub], od)
 
 
+@pytest.mark.parametrize("use_asm", [1, 0])
 @pytest.mark.parametrize("share", [1, 2])
 @pytest.mark.parametrize("rp,dsplit", [(72, 1), (109, 0)])
-def test_every_walk_kernel_vs_oracle(kng, orc, share, rp, dsplit):
-    """All four instantiations of the walk kernel -- share 1/2 x {low-word distance streaming, both words} --
-    as the engine itself selects them: a 72-bit range streams only the low word, BASELINE configs[3]'s 109-bit range
-    (jump distances around 2^54) streams both.  States and the exact DP multiset over two launches."""
+def test_every_walk_kernel_vs_oracle(kng, orc, share, rp, dsplit, use_asm):
+    """All eight instantiations of the walk kernel -- share 1/2 x {low-word distance streaming, both words} x {scheduled
+    asm loop, compiler-scheduled loop} -- as the engine itself selects them: a 72-bit range streams only the low word,
+    BASELINE configs[3]'s 109-bit range (jump distances around 2^54) streams both.  States and the exact DP multiset
+    over two launches."""
     grid = (4, 4)
     n = grid[0] * grid[1] * 128
     x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=1000 + rp + share)
     jd, jx, jy, _ = orc.jump_table(rp)
     mask = orc.dp_mask(5)
-    eng = kng.GPUEngine(grid[0], grid[1], 0, 1 << 16, share=share, group=16)
+    eng = kng.GPUEngine(grid[0], grid[1], 0, 1 << 16, share=share, group=16, asm=use_asm)
     eng.SetParams(mask, jd, jx, jy)
-    assert eng.get_option("dsplit") == dsplit and eng.get_option("share") == share
+    assert eng.get_option("dsplit") == dsplit and eng.get_option("share") == share and eng.get_option("asm") == use_asm
     eng.SetWildOffset(wild_offset)
     eng.SetKangaroos(x, y, ints_to_array(true_d))
     ox, oy = x.copy(), y.copy()

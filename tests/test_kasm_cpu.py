@@ -1,0 +1,149 @@
+"""The generated gfx950 code (tools/kasm.py + tools/kfield.py + tools/gen_*.py), executed on the CPU.
+
+`tools/kasm_emu.py` runs the PRINTED text -- final schedule, physical registers -- lane by lane, so these tests cover the
+arithmetic, the list scheduler's ordering and the register allocator without a GPU:
+  * fe_mul as one statement (kng_mulasm.h) and fe_sub against the reference's golden vectors; a lane may only differ
+    from the reference when it raised the exact-path flag;
+  * the whole walk loop (kng_walk_asm.h) against an integer model of walk_body's data flow: states, running products,
+    DP records, both distance layouts, G = 1 and 2, exact-path exits and re-entry, 64-lane waves;
+  * the static verifier finds no hazard / s_waitcnt problem, and the headers in the tree are what the generators emit.
+Hazard TIMING cannot be emulated; the distances are LLVM's (kasm.WS_*) and are checked statically by kasm.verify.
+"""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import gen_mulasm  # noqa: E402
+import gen_walk_asm  # noqa: E402
+import kasm  # noqa: E402
+import kfield  # noqa: E402
+import kwalk_emu  # noqa: E402
+from kasm_emu import Emu  # noqa: E402
+
+
+def _run_binary_op(text, operands, cases, W=16):
+    """operands: dict name -> list of 8 register numbers (a, b, r) + 'rare' pair + 'k977'"""
+    out = []
+    for c0 in range(0, len(cases), W):
+        chunk = cases[c0:c0 + W]
+        e = Emu(lanes=W)
+        e.exec = (1 << len(chunk)) - 1
+        for l, (x, y) in enumerate(chunk):
+            for i in range(8):
+                e.v[operands["a"][i]][l] = (x >> (32 * i)) & 0xFFFFFFFF
+                e.v[operands["b"][i]][l] = (y >> (32 * i)) & 0xFFFFFFFF
+            if "v977" in operands:
+                e.v[operands["v977"]][l] = 977
+        e.s[operands["k977"]] = 977
+        e.run(text)
+        rare = e.s[operands["rare"]] | (e.s[operands["rare"] + 1] << 32)
+        for l in range(len(chunk)):
+            out.append((sum(e.v[operands["r"][i]][l] << (32 * i) for i in range(8)), (rare >> l) & 1))
+    return out
+
+
+def test_fe_mul_statement_against_golden_vectors(golden):
+    """kng_mulasm.h's statement with its operands bound to registers: every golden ModMulK1 vector (incl. the lazy-fold
+    corner cases) is reproduced exactly, or the lane asks for the exact path -- and only edge operands do."""
+    A, used = gen_mulasm.build()
+    text = kasm.listing(A, comments=False)
+    bind = {f"%{i}": f"v{i}" for i in range(8)}
+    bind.update({f"%{9 + i}": f"v{16 + i}" for i in range(8)})
+    bind.update({f"%{17 + i}": f"v{32 + i}" for i in range(8)})
+    bind.update({"%8": "s[2:3]", "%25": "s1"})
+    text = [re.sub(r"%(\d+)", lambda m: bind["%" + m.group(1)], t) for t in text]
+    assert min(used["v"]) > 40 and min(used["s"]) > 3
+    cases = [(int(a, 16), int(b, 16)) for a, b, _ in golden["modmul"]]
+    want = [int(r, 16) & ((1 << 256) - 1) for _, _, r in golden["modmul"]]
+    got = _run_binary_op(text, {"a": list(range(16, 24)), "b": list(range(32, 40)), "r": list(range(8)), "rare": 2, "k977": 1}, cases)
+    flagged = 0
+    for (g, rare), w, (a, b) in zip(got, want, cases):
+        assert kfield.ref_mul(a, b) == w  # the integer restatement the loop model uses is the reference's integer
+        if rare:
+            flagged += 1
+        else:
+            assert g == w, f"{a:x} * {b:x}"
+    # random operands practically never need the exact path; the golden set is edge-heavy
+    import random
+
+    rnd = random.Random(5)
+    rcases = [(rnd.getrandbits(256), rnd.getrandbits(256)) for _ in range(256)]
+    rgot = _run_binary_op(text, {"a": list(range(16, 24)), "b": list(range(32, 40)), "r": list(range(8)), "rare": 2, "k977": 1}, rcases)
+    assert all(not rare and g == kfield.ref_mul(a, b) for (g, rare), (a, b) in zip(rgot, rcases))
+    assert 0 < flagged < len(cases) // 2
+
+
+def test_fe_sub_against_golden_vectors(golden):
+    A = kasm.Asm()
+    a = [A.v(f"a{i}", pinned=True) for i in range(8)]
+    b = [A.v(f"b{i}", pinned=True) for i in range(8)]
+    rare, k977, v977 = A.st("rare", 2, pinned=True), A.s("k977", pinned=True), A.v("v977", pinned=True)
+    F = kfield.Field(A, k977, rare)
+    out = kfield.fe_sub(F, a, b, k977_v=v977)
+    A.keep(*out, rare, k977)
+    kasm.schedule(A)
+    kasm.allocate(A, list(range(0, 64)), list(range(0, 32)))
+    assert not kasm.verify(A)
+    text = kasm.listing(A, comments=False)
+    cases = [(int(x, 16), int(y, 16)) for x, y, _ in golden["modsub"]]
+    want = [int(r, 16) & ((1 << 256) - 1) for _, _, r in golden["modsub"]]  # the reference Int is 320-bit signed: low 256 bits
+    ops = {"a": [r.phys for r in a], "b": [r.phys for r in b], "r": [r.phys for r in out], "rare": rare[0].phys, "k977": k977.phys, "v977": v977.phys}
+    got = _run_binary_op(text, ops, cases)
+    for (g, rare_), w, (x, y) in zip(got, want, cases):
+        assert kfield.ref_sub(x, y) == w
+        assert rare_ or g == w, f"{x:x} - {y:x}"
+    assert sum(r for _, r in got) < len(cases) // 4
+
+
+@pytest.mark.parametrize("dsplit", [True, False])
+def test_walk_loop_verifies_clean(dsplit):
+    lp, used, problems = gen_walk_asm.generate(dsplit)
+    assert problems == []
+    st = kasm.stats(lp.A, blocks={"A", "B", "commit", "next"})
+    assert st.get("nop", 0) <= 4, st  # the point of the exercise: independent work pads the carry chains
+    assert max(used["v"]) < 256 and max(used["s"]) < 100
+
+
+@pytest.mark.parametrize("case", [
+    dict(L=8, G=5, steps=3, dsplit=True),
+    dict(L=8, G=5, steps=2, dsplit=False, jd_bits=100),
+    dict(L=8, G=1, steps=2, dsplit=True),
+    dict(L=8, G=2, steps=3, dsplit=False, jd_bits=90),
+    dict(L=8, G=4, steps=2, dsplit=True, jd_bits=64, seed=3),   # low-word carries: exact-path exits nearly every iteration
+    dict(L=64, G=3, steps=2, dsplit=True, dp_bits=2, jd_bits=40, seed=5),  # full wave, several DPs per wave-iteration
+    dict(L=64, G=2, steps=2, dsplit=False, dp_bits=1, jd_bits=70, seed=6),
+])
+def test_walk_loop_against_integer_model(case):
+    stats = kwalk_emu.run_case(verbose=False, **case)
+    if case.get("jd_bits") == 64:
+        assert stats.get("rare_exits", 0) > 0
+
+
+def test_walk_loop_dp_overflow_is_counted_not_stored():
+    """records beyond max_found are counted (the host reports them lost) but not written"""
+    jx, jy, jd = kwalk_emu.random_table(9, 40)
+    m = kwalk_emu.Model(64, 2, jx, jy, jd, dp_mask=0, seed=9)  # mask 0: every point is distinguished
+    acc = m.pass0()
+    h = kwalk_emu.Harness(m, True, max_found=50)
+    inv = [pow(a % kfield.P, kfield.P - 2, kfield.P) for a in acc]
+    h.run_step(inv, acc, backward=True, stats={})
+    n, recs = h.dp_records()
+    assert n == 128 and len(recs) == 50
+    assert set(recs) <= set(m.dps) and len(set(recs)) == 50
+
+
+def test_generated_headers_are_current():
+    for gen, hdr in (("gen_mulasm.py", "kng_mulasm.h"), ("gen_walk_asm.py", "kng_walk_asm.h")):
+        path = os.path.join(ROOT, "kangaroo_amd", "csrc", hdr)
+        before = open(path).read()
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen)], check=True, capture_output=True)
+        after = open(path).read()
+        assert before == after, f"{hdr} is stale: run tools/{gen}"
