@@ -40,6 +40,7 @@ RANGE_START = int("B60E83280258A40F9CDF1649744D730D6E939DE92A2B" + "0" * 20, 16)
 KEY = RANGE_START + 0xC0FFEE123456789ABCD  # 80-bit offset, answer known
 ALG_BYTES_PER_JUMP = 160  # read + write of x(32) y(32) d(16): SURVEY.md 8d
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0  # MI355X_MICROARCH.md: measured copy ceiling
 # BASELINE configs[3]: puzzle #110 (reference puzzle32.txt:6-9), interval [2^109, 2^110 - 1] -> rangePower 109, DP 25
 P110_START, P110_END = 0x2000000000000000000000000000, 0x3FFFFFFFFFFFFFFFFFFFFFFFFFFF
 P110_PUB = "0309976BA5570966BF889196B7FDF5A0F9A1E9AB340556EC29F8BB60599616167D"
@@ -113,9 +114,27 @@ def cpu_baseline(seconds: float = 20.0) -> dict:
 
 
 def _kernel_name(eng) -> str:
-    """Name of the walk kernel the engine launches with its current options (as rocprofv3 prints it)."""
-    share, ds = eng.get_option("share"), eng.get_option("dsplit")
-    return f"kng_walk_share_kernel<{share}, {'true' if ds else 'false'}>"
+    """Name of the walk kernel the engine launches with its current options (as rocprofv3 prints it).  `eng`: anything
+    with get_option(key) -- a GPUEngine, or one GPU of a Solver."""
+    share, ds, am = eng.get_option("share"), eng.get_option("dsplit"), eng.get_option("asm")
+    return f"kng_walk_share_kernel<{share}, {'true' if ds else 'false'}, {'true' if am else 'false'}>"
+
+
+def _roofline(kernel, kms, n, nb_run, group, note=None, sustained_ms=None):
+    alg = n * nb_run * ALG_BYTES_PER_JUMP
+    achieved = alg / (kms * 1e-3) / 1e9
+    traffic, tsrc = _recorded_traffic(n, group, kernel)
+    r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+         "frac_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4), "peak_achievable": HBM_ACHIEVABLE_GBS,
+         "traffic": traffic, "traffic_source": tsrc, "kernel": kernel, "kernel_ms": round(kms, 3), "alg_bytes_per_launch": alg}
+    if traffic:
+        r["traffic_gbs"] = round(traffic / (kms * 1e-3) / 1e9, 1)
+    if sustained_ms:
+        r["frac_sustained"] = round(alg / (sustained_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        r["sustained_kernel_ms"] = round(sustained_ms, 3)
+    if note:
+        r["note"] = note
+    return r
 
 
 def _decompress(pub_hex):
@@ -135,18 +154,38 @@ def _shifted_key(hl, key_xy, range_start):
     return x, y
 
 
+KERNEL_SOURCES = ("kng_engine.hip", "kng_field.h", "kng_mul32.h", "kng_mulasm.h", "kng_walk_asm.h", "kng_modinv.h")
+
+
+def kernel_source_blobs() -> dict:
+    """`git hash-object` of the files the walk kernel is compiled from (computed here: the GPU box has no .git)"""
+    import hashlib
+
+    out = {}
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "kangaroo_amd", "csrc", name), "rb") as f:
+            data = f.read()
+        out[name] = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    return out
+
+
 def _recorded_traffic(n, group, kernel):
-    """HBM bytes per launch from the last PMC pass (tools/gpu_round.sh keeps profiles/traffic.json current and fails
-    when it drifts); only quoted for the kernel and geometry it was measured on."""
+    """HBM bytes per launch from the last PMC pass (profiles/traffic.json, written by tools/gpu_round.sh).  Quoted only
+    for the kernel and geometry it was measured on AND only while the kernel's sources are byte-identical to the ones it
+    was measured on (git blob ids recorded with the figure); otherwise traffic is null and the reason is given."""
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(tfile) as f:
             tj = json.load(f)
-        if tj.get("kangaroos") == n and tj.get("group") == group and tj.get("kernel") == kernel:
-            return tj.get("hbm_bytes_per_launch"), tj.get("source")
-    except Exception:
-        pass
-    return None, None
+    except Exception as e:
+        return None, f"no recorded figure ({e})"
+    if not (tj.get("kangaroos") == n and tj.get("group") == group and tj.get("kernel") == kernel):
+        return None, f"recorded for {tj.get('kernel')} at {tj.get('kangaroos')} kangaroos / group {tj.get('group')}, not for this run"
+    now, then = kernel_source_blobs(), tj.get("source_blobs") or {}
+    changed = sorted(k for k in now if then.get(k) != now[k])
+    if changed:
+        return None, f"stale: {', '.join(changed)} changed since the PMC pass ({tj.get('source')})"
+    return tj.get("hbm_bytes_per_launch"), tj.get("source")
 
 
 def _timed_engine(k, hl, dev, gx, gy, range_power, key_xy, dp, steps, warmup, seed, **opts):
@@ -194,9 +233,14 @@ def bench_multi(args, ranks, n_gpus):
 
     from kangaroo_amd.dist import timed_on_rank0
 
+    from kangaroo_amd.dist import RankFailure
+
     out = None
     job = {}
+    prep_error = None
+    s = None
     if ranks.rank == 0:
+      try:  # a failure here must reach the other ranks (they are about to wait in a barrier): all_ok() below
         import kangaroo_amd as k
         import kangaroo_amd.hostlib as hl
         from kangaroo_amd import solver as sv
@@ -204,7 +248,8 @@ def bench_multi(args, ranks, n_gpus):
         k.load_library()
         devices = tuple(int(v) for v in args.devices.split(",")) if args.devices else tuple(range(n_gpus))
         if len(devices) != n_gpus or max(devices) >= k.device_count():
-            raise SystemExit(f"--gpus {n_gpus}: devices {devices} but {k.device_count()} HIP devices are visible")
+            raise RuntimeError(f"--gpus {n_gpus}: rank 0 drives devices {devices} but sees only {k.device_count()} HIP device(s) "
+                               f"(ROCR_/HIP_VISIBLE_DEVICES per rank?); the job is one process over all GPUs and one shared DP table")
         info = k.device_info(devices[0])
         if args.grid:
             gx, gy = (int(v) for v in args.grid.split(","))
@@ -219,7 +264,21 @@ def bench_multi(args, ranks, n_gpus):
         s.prepare()  # engines, herds (built on the GPUs), W discarded launches per GPU
         log(f"{n_gpus} x {info['name']}: 2^{np.log2(n):.0f} kangaroos each, dp {dp}; prepared in {time.time() - t0:.1f} s")
         job["run"] = lambda: (s.start(), s.wait(600))
-    elapsed = timed_on_rank0(ranks, job.get("run"))
+      except BaseException as e:  # noqa: BLE001
+        prep_error = e
+    if not ranks.all_ok(prep_error is None):
+        if prep_error is not None:
+            log(f"bench --gpus {n_gpus}: rank 0 could not prepare the job: {prep_error!r}")
+        if s is not None:
+            s.close()
+        ranks.abort()
+        raise SystemExit(1)  # EVERY rank leaves non-zero, promptly
+    try:
+        elapsed = timed_on_rank0(ranks, job.get("run"))
+    except RankFailure as e:
+        log(f"bench --gpus {n_gpus}: {e}")
+        ranks.abort()
+        raise SystemExit(1)
     if ranks.rank == 0:
         st = s.stats()
         per_gpu = []
@@ -229,14 +288,16 @@ def bench_multi(args, ranks, n_gpus):
             per_gpu.append({"gpu": g, "device": devices[g], "launches": gs["launches"], "kernel_ms": round(kms, 3),
                             "kernel_rate": round(gs["kangaroos"] * k.KNG_NB_RUN / (kms * 1e-3) / 1e6, 1)})
         load = s.consumer_load()
+
+        class _Gpu0:  # the walk kernel that actually ran, from the engine of GPU 0 (every GPU gets the same options)
+            get_option = staticmethod(lambda key: s.gpu_option(0, key))
+
+        kernel, group = _kernel_name(_Gpu0), s.gpu_option(0, "group")
         s.stop()
         s.close()
         assert all(p["launches"] == args.steps for p in per_gpu), per_gpu
         jumps = n_gpus * n * k.KNG_NB_RUN * args.steps
         kms = float(np.mean([p["kernel_ms"] for p in per_gpu]))
-        achieved = n * k.KNG_NB_RUN * ALG_BYTES_PER_JUMP / (kms * 1e-3) / 1e9
-        kernel = "kng_walk_share_kernel<2, true>"
-        traffic, tsrc = _recorded_traffic(n, 64, kernel)
         out = {
             "metric": "kangaroo jumps/sec (MK/s)", "value": round(jumps / elapsed / 1e6, 2), "unit": "MK/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
@@ -251,10 +312,9 @@ def bench_multi(args, ranks, n_gpus):
             },
             "per_gpu": per_gpu,
             "kernel_rate_sum": round(sum(p["kernel_rate"] for p in per_gpu), 1),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "traffic_source": tsrc, "kernel": kernel, "kernel_ms": round(kms, 3),
-                         "alg_bytes_per_launch": n * k.KNG_NB_RUN * ALG_BYTES_PER_JUMP, "note": "per GPU, mean over GPUs"},
+            "roofline": _roofline(kernel, kms, n, k.KNG_NB_RUN, group, note="per GPU, mean over GPUs"),
         }
+        out["config"]["control_plane"] = f"{ranks.backend} (CPU): no collective kernel on a measured GPU"
     ranks.close()
     if out is not None:
         print(json.dumps(out), flush=True)
@@ -275,12 +335,11 @@ def main():
     ap.add_argument("--devices", default="", help="N > 1: explicit device list, e.g. 0,0 to exercise the multi-GPU path on one device (default 0..N-1)")
     args = ap.parse_args()
 
-    # torch is plumbing here: rendezvous/barrier over RCCL and the cross-rank max of the timings
-    import torch  # noqa: F401
+    # torch is plumbing here: rendezvous, barriers and the cross-rank max of the timings (CPU-side, gloo)
 
     from kangaroo_amd.dist import Ranks, timed_steps, whole_job_rate
 
-    ranks = Ranks(backend="nccl")
+    ranks = Ranks()  # gloo: the control plane stays off the GPUs (kangaroo_amd/dist.py)
     rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
     if world != args.gpus and world > 1:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
@@ -372,8 +431,7 @@ def main():
     jumps_per_step = n * k.KNG_NB_RUN
     value = whole_job_rate(ranks, jumps_per_step, args.steps, elapsed) / 1e6  # MK/s, whole job
     kms = float(np.mean(kernel_ms))
-    achieved = jumps_per_step * ALG_BYTES_PER_JUMP / (kms * 1e-3) / 1e9  # GB/s, per GPU
-    traffic, traffic_source = _recorded_traffic(n, eng.get_option("group"), _kernel_name(eng))
+    roof = _roofline(_kernel_name(eng), kms, n, k.KNG_NB_RUN, eng.get_option("group"))
     out = {
         "metric": "kangaroo jumps/sec (MK/s)",
         "value": round(value, 2),
@@ -391,17 +449,12 @@ def main():
             "workload": f"80-bit range single key, auto DP {dp}, herd {gx}x{gy}x128 = 2^{np.log2(n):.0f} kangaroos/GPU, "
                         f"{k.KNG_NB_RUN} jumps/launch",
             "range_power": RANGE_POWER, "dp": dp, "grid": [gx, gy], "kangaroos_per_gpu": n,
-            "group": eng.get_option("group"), "lanes": eng.get_option("lanes"), "share": eng.get_option("share"), "device": info["name"], "arch": info["arch"],
+            "group": eng.get_option("group"), "lanes": eng.get_option("lanes"), "share": eng.get_option("share"), "asm_loop": eng.get_option("asm"),
+            "device": info["name"], "arch": info["arch"],
             "parallelism": f"independent herds x{n_gpus}, no collective",
             "dps_per_step": round(dps / args.steps, 1), "dps_lost": lost,
         },
-        "roofline": {
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": _kernel_name(eng),
-            "kernel_ms": round(kms, 3),
-            "alg_bytes_per_launch": jumps_per_step * ALG_BYTES_PER_JUMP,
-        },
+        "roofline": roof,
     }
     eng.close()
     if rank == 0 and n_gpus == 1 and not args.no_secondary:
@@ -419,6 +472,9 @@ def main():
             st = s.stats()
             s.stop()
             s.close()
+            # the sustained figure next to the 0.5-second headline: the same kernel over the pipeline's longer run
+            roof["frac_sustained"] = round(jumps_per_step * ALG_BYTES_PER_JUMP / (st["kernel_ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            roof["sustained_kernel_ms"] = round(st["kernel_ms_avg"], 3)
             out["pipeline"] = {"value": round(st["jumps"] / st["seconds"] / 1e6, 2), "unit": "MK/s", "launches": st["launches"],
                                "kernel_ms_avg": round(st["kernel_ms_avg"], 3), "dps": st["dps"], "dps_lost": st["dps_lost"],
                                "what": "kngs_* solver: async DP drain + sharded DP table, wall clock incl. first and last launch"}

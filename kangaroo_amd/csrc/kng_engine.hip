@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -332,7 +333,9 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
             // (readfirstlane: the "s" operands must be provably wave-uniform for the compiler)
             const uint32_t ldstab = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)tab); // LDS byte address = low half of the flat address
             const int32_t stride = __builtin_amdgcn_readfirstlane(backward ? -(int32_t)(L * 16) : (int32_t)(L * 16));
-            const uint64_t aargs = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(a.asm_args >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)a.asm_args);
+            // (the builtin returns int: widen through uint32_t, or a low word with bit 31 set sign-extends over the high word)
+            const uint64_t aargs = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a.asm_args >> 32)) << 32) |
+                                   (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a.asm_args);
             uint32_t iv[8], ac[8] = {1, 0, 0, 0, 0, 0, 0, 0}; // acc' = acc * dx2 with acc = 1 for the first kangaroo (exact)
             fe_to32(iv, inv);
             uint32_t k = 0;
@@ -841,6 +844,10 @@ int kng_set_params(kng_engine *h, uint64_t dp_mask, const uint64_t *jd, const ui
         aa[s].dp_mask = dp_mask; aa[s].dp_count = (uint64_t)h->dp_count[s]; aa[s].dp_items = (uint64_t)h->dp_items[s];
         aa[s].max_found = h->max_found; aa[s].pad = 0;
     }
+    if (getenv("KNG_TRACE"))
+        fprintf(stderr, "kng: planes %p..%p (n=%llu) jtab %p asm_args %p dp_count %p %p dp_items %p %p max_found %u\n", (void *)h->planes,
+                (void *)(h->planes + 7 * h->n), (unsigned long long)h->n, (void *)h->jtab, (void *)h->asm_args, (void *)h->dp_count[0],
+                (void *)h->dp_count[1], (void *)h->dp_items[0], (void *)h->dp_items[1], h->max_found);
     // stream-ordered after any in-flight launch
     HIP_TRY(hipMemcpyAsync(h->jtab, tab, sizeof tab, hipMemcpyHostToDevice, h->walk));
     HIP_TRY(hipMemcpyAsync(h->asm_args, aa, sizeof aa, hipMemcpyHostToDevice, h->walk));

@@ -677,6 +677,15 @@ int kngs_gpu_stats(const kngs_solver *s, int gpu, uint64_t *launches, double *ke
     return 0;
 }
 
+int kngs_gpu_option(const kngs_solver *s, int gpu, const char *key, int64_t *value) {
+    if (!s || !key || !value) return fail("null argument");
+    if (gpu < 0 || (size_t)gpu >= s->workers.size()) return fail("no gpu %d", gpu);
+    const Worker *w = s->workers[(size_t)gpu];
+    if (!w->eng) return fail("gpu %d has no engine yet (kngs_prepare)", gpu);
+    if (kng_get_option(w->eng, key, value) != KNG_OK) return fail("%s", kng_last_error());
+    return 0;
+}
+
 const kngt_table *kngs_table(const kngs_solver *s) { return s ? s->table : nullptr; }
 
 int kngs_wait(kngs_solver *s, double seconds) {

@@ -94,6 +94,9 @@ int kngs_save(kngs_solver *s, const char *path, int with_kangaroos);
 int kngs_collision_key(const kngs_solver *s, const uint64_t tame_d[4], const uint64_t wild_d[4], uint64_t priv[4]);
 /* per-GPU figures of this run: launches done, summed walk-kernel time (HIP events), herd size */
 int kngs_gpu_stats(const kngs_solver *s, int gpu, uint64_t *launches, double *kernel_ms_sum, uint64_t *kangaroos);
+/* an option of one GPU's engine as kng_get_option reads it ("group", "lanes", "share", "dsplit", "asm", ...): lets a caller
+ * name the walk kernel that ran instead of assuming the defaults.  Valid after kngs_prepare / kngs_start. */
+int kngs_gpu_option(const kngs_solver *s, int gpu, const char *key, int64_t *value);
 /* points each consumer thread has taken off its queue; returns the number of consumers */
 int kngs_consumer_load(const kngs_solver *s, uint64_t *handled, int cap);
 

@@ -284,6 +284,12 @@ class Solver:
         self._check(self._L.kngs_gpu_stats(self._h, gpu, C.byref(l), C.byref(ms), C.byref(n)))
         return {"launches": int(l.value), "kernel_ms_sum": float(ms.value), "kangaroos": int(n.value)}
 
+    def gpu_option(self, gpu: int, key: str) -> int:
+        """an option of one GPU's engine (kng_get_option): group, lanes, share, dsplit, asm, ..."""
+        v = C.c_int64(0)
+        self._check(self._L.kngs_gpu_option(self._h, gpu, key.encode(), C.byref(v)))
+        return int(v.value)
+
     def consumer_load(self) -> list:
         buf = (C.c_uint64 * 64)()
         n = self._check(self._L.kngs_consumer_load(self._h, buf, 64))

@@ -320,9 +320,12 @@ def generate(dsplit, vpool=VPOOL, spool=SPOOL):
 
 def c_string(lines):
     out = []
+    pad = int(os.environ.get("KASM_PARANOID", "0"))  # debugging aid: s_nop behind every instruction (hazard or logic?)
     for t in lines:
         t = t.split("\t;")[0].rstrip()
         out.append('        "' + t.replace("\t", " ").strip() + '\\n"')
+        if pad and not t.strip().endswith(":") and not t.strip().startswith(";"):
+            out.append(f'        "s_nop {pad - 1}\\n"')
     return "\n".join(out)
 
 
