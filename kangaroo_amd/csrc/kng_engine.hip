@@ -348,7 +348,8 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
                 if (k >= Gs) break;
                 // exact path: some lane of this wave needs the general arithmetic for kangaroo k; nothing of it was stored
                 KNG_RARE_PATH();
-                fe xi = fe_from32(iv), xa = fe_from32(ac);
+                // the statement updates the running product in place: its value before kangaroo k is what kangaroo k - 1 stored
+                fe xi = fe_from32(iv), xa = k ? ld_prod(a.s01, a.s23, slot(k - 1)) : fe_one();
                 const size_t idx = slot(k);
                 const bool have_nb = k + 1 < G;
                 const fe nb = have_nb ? ld_prod(a.s01, a.s23, slot(k + 1)) : fe_one();
@@ -600,6 +601,13 @@ struct kng_engine {
     // pinned host memory
     uint32_t *h_count[2] = {nullptr, nullptr};
     DpRecord *h_items = nullptr;
+    // option "dp_ring": the kernel writes its DP records straight into pinned, device-mapped host memory (one buffer per
+    // launch slot; the counter stays in device memory -- an atomic per DP-bearing wave-step across PCIe would stall the
+    // walk -- and lands last, stream-ordered behind the kernel).  No second hop, no host-synchronous copy in land_points.
+    int dp_ring = 0;
+    DpRecord *ring[2] = {nullptr, nullptr};     // host view
+    DpRecord *ring_dev[2] = {nullptr, nullptr}; // device view of the same memory
+    const DpRecord *view = nullptr;             // where the records of the last drained launch are
     v16 *h_stage = nullptr;
     size_t stage_kang = 0;
     // streams / events
@@ -625,6 +633,21 @@ static void decide_dsplit(kng_engine *h) {
     const bool possible = h->jd_max != UINT64_MAX;
     h->dsplit_on = possible && (h->dsplit == 1 || (h->dsplit == -1 && h->jd_max < (1ULL << 50)));
 }
+static DpRecord *dp_buffer(const kng_engine *h, int s) { return h->dp_ring ? h->ring_dev[s] : h->dp_items[s]; }
+// constants of the scheduled loop (WalkAsmArgs), one block per DP buffer; stream-ordered behind any in-flight launch
+static int upload_loop_args(kng_engine *h) {
+    WalkAsmArgs aa[2];
+    for (int s = 0; s < 2; s++) {
+        aa[s].x01 = (uint64_t)plane(h, 0); aa[s].x23 = (uint64_t)plane(h, 1); aa[s].y01 = (uint64_t)plane(h, 2); aa[s].y23 = (uint64_t)plane(h, 3);
+        aa[s].dlo = (uint64_t)dplane(h, 0); aa[s].dhi = (uint64_t)dplane(h, 1);
+        aa[s].s01 = (uint64_t)plane(h, 5); aa[s].s23 = (uint64_t)plane(h, 6);
+        aa[s].dp_mask = h->dp_mask; aa[s].dp_count = (uint64_t)h->dp_count[s]; aa[s].dp_items = (uint64_t)dp_buffer(h, s);
+        aa[s].max_found = h->max_found; aa[s].pad = 0;
+    }
+    HIP_TRY(hipMemcpy(h->asm_args, aa, sizeof aa, hipMemcpyHostToDevice)); // tiny and synchronous: `aa` lives on this stack
+    return KNG_OK;
+}
+
 extern "C" {
 
 const char *kng_last_error(void) { return g_err.c_str(); }
@@ -755,6 +778,8 @@ void kng_destroy(kng_engine *h) {
         if (h->ev_done[s]) (void)hipEventDestroy(h->ev_done[s]);
     }
     if (h->h_items) (void)hipHostFree(h->h_items);
+    for (int s = 0; s < 2; s++)
+        if (h->ring[s]) (void)hipHostFree(h->ring[s]);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->walk) (void)hipStreamDestroy(h->walk);
     if (h->copy) (void)hipStreamDestroy(h->copy);
@@ -790,6 +815,21 @@ int kng_set_option(kng_engine *h, const char *key, int64_t value) {
     } else if (k == "share") {
         if (value < 1 || value > 2) return fail(KNG_E_ARG, "share must be 1 or 2");
         h->share = (int)value;
+    } else if (k == "dp_ring") {
+        if (value < 0 || value > 1) return fail(KNG_E_ARG, "dp_ring must be 0 or 1");
+        HIP_TRY(hipSetDevice(h->dev));
+        for (int s = 0; value && s < 2; s++) {
+            if (h->ring[s]) continue;
+            hipError_t e = hipHostMalloc((void **)&h->ring[s], (size_t)h->max_found * sizeof(DpRecord), hipHostMallocMapped | hipHostMallocPortable);
+            if (e != hipSuccess) return fail(KNG_E_ALLOC, "pinned DP ring (%zu bytes): %s", (size_t)h->max_found * sizeof(DpRecord), hipGetErrorString(e));
+            HIP_TRY(hipHostGetDevicePointer((void **)&h->ring_dev[s], h->ring[s], 0));
+        }
+        h->dp_ring = (int)value;
+        h->slot_ready = -1; // points of a launch waited for but not yet drained live in the other kind of buffer
+        if (h->have_params) {
+            int rc = upload_loop_args(h);
+            if (rc != KNG_OK) return rc;
+        }
     } else if (k == "asm") {
         if (value < 0 || value > 1) return fail(KNG_E_ARG, "asm must be 0 or 1");
         if (value && (h->n > (1ull << 28) || h->max_found > (1u << 26))) return fail(KNG_E_ARG, "the scheduled loop addresses at most 2^28 kangaroos and 2^26 DP records");
@@ -809,6 +849,7 @@ int kng_get_option(const kng_engine *h, const char *key, int64_t *value) {
     else if (k == "lanes") *value = h->lanes;
     else if (k == "share") *value = h->share;
     else if (k == "asm") *value = h->use_asm;
+    else if (k == "dp_ring") *value = h->dp_ring;
     else if (k == "dsplit") *value = h->dsplit_on ? 1 : 0;
     else if (k == "cu_count") *value = h->cu_count;
     else if (k == "waves_per_cu") *value = h->cu_count ? (int64_t)((h->lanes / 64 + h->cu_count - 1) / h->cu_count) : 0;
@@ -835,24 +876,16 @@ int kng_set_params(kng_engine *h, uint64_t dp_mask, const uint64_t *jd, const ui
         else if (h->jd_max != UINT64_MAX && jd[2 * j] > h->jd_max) h->jd_max = jd[2 * j];
     }
     decide_dsplit(h);
-    // constants of the scheduled loop, one block per DP buffer
-    WalkAsmArgs aa[2];
-    for (int s = 0; s < 2; s++) {
-        aa[s].x01 = (uint64_t)plane(h, 0); aa[s].x23 = (uint64_t)plane(h, 1); aa[s].y01 = (uint64_t)plane(h, 2); aa[s].y23 = (uint64_t)plane(h, 3);
-        aa[s].dlo = (uint64_t)dplane(h, 0); aa[s].dhi = (uint64_t)dplane(h, 1);
-        aa[s].s01 = (uint64_t)plane(h, 5); aa[s].s23 = (uint64_t)plane(h, 6);
-        aa[s].dp_mask = dp_mask; aa[s].dp_count = (uint64_t)h->dp_count[s]; aa[s].dp_items = (uint64_t)h->dp_items[s];
-        aa[s].max_found = h->max_found; aa[s].pad = 0;
-    }
+    h->dp_mask = dp_mask;
     if (getenv("KNG_TRACE"))
         fprintf(stderr, "kng: planes %p..%p (n=%llu) jtab %p asm_args %p dp_count %p %p dp_items %p %p max_found %u\n", (void *)h->planes,
                 (void *)(h->planes + 7 * h->n), (unsigned long long)h->n, (void *)h->jtab, (void *)h->asm_args, (void *)h->dp_count[0],
                 (void *)h->dp_count[1], (void *)h->dp_items[0], (void *)h->dp_items[1], h->max_found);
     // stream-ordered after any in-flight launch
     HIP_TRY(hipMemcpyAsync(h->jtab, tab, sizeof tab, hipMemcpyHostToDevice, h->walk));
-    HIP_TRY(hipMemcpyAsync(h->asm_args, aa, sizeof aa, hipMemcpyHostToDevice, h->walk));
+    int rc = upload_loop_args(h);
+    if (rc != KNG_OK) return rc;
     HIP_TRY(hipStreamSynchronize(h->walk));
-    h->dp_mask = dp_mask;
     h->have_params = true;
     return KNG_OK;
 }
@@ -987,7 +1020,7 @@ int kng_launch(kng_engine *h) {
     a.jtab = h->jtab;
     a.dp_mask = h->dp_mask;
     a.dp_count = h->dp_count[s];
-    a.dp_items = h->dp_items[s];
+    a.dp_items = dp_buffer(h, s);
     a.max_found = h->max_found;
     a.lanes = h->lanes;
     a.group = h->group;
@@ -1070,9 +1103,14 @@ static int land_points(kng_engine *h, uint32_t cap, uint32_t *found_out, uint32_
         lost += found - cap;
         found = cap;
     }
-    if (found) {
-        HIP_TRY(hipMemcpyAsync(h->h_items, h->dp_items[s], (size_t)found * sizeof(DpRecord), hipMemcpyDeviceToHost, h->copy));
-        HIP_TRY(hipStreamSynchronize(h->copy));
+    if (h->dp_ring) {
+        h->view = h->ring[s]; // the kernel wrote them here; complete since the launch's event fired (kng_wait)
+    } else {
+        if (found) {
+            HIP_TRY(hipMemcpyAsync(h->h_items, h->dp_items[s], (size_t)found * sizeof(DpRecord), hipMemcpyDeviceToHost, h->copy));
+            HIP_TRY(hipStreamSynchronize(h->copy));
+        }
+        h->view = h->h_items;
     }
     *found_out = found;
     *lost_out = lost;
@@ -1089,10 +1127,10 @@ int kng_drain(kng_engine *h, kng_item *items, uint32_t cap, uint32_t *n_items, u
     const int rc = land_points(h, cap, &found, &lost);
     if (rc != KNG_OK) return rc;
     for (uint32_t i = 0; i < found; i++) {
-        memcpy(items[i].x, h->h_items[i].x, 32);
-        items[i].d[0] = h->h_items[i].d[0];
-        items[i].d[1] = h->h_items[i].d[1];
-        items[i].kidx = h->h_items[i].kidx;
+        memcpy(items[i].x, h->view[i].x, 32);
+        items[i].d[0] = h->view[i].d[0];
+        items[i].d[1] = h->view[i].d[1];
+        items[i].kidx = h->view[i].kidx;
     }
     *n_items = found;
     if (n_lost) *n_lost = lost;
@@ -1103,12 +1141,13 @@ static_assert(sizeof(kng_dp_record) == sizeof(DpRecord), "kng_dp_record is the r
 
 int kng_drain_view(kng_engine *h, const kng_dp_record **records, uint32_t *n_items, uint32_t *n_lost) {
     if (!h || !records || !n_items) return fail(KNG_E_ARG, "null argument");
-    *records = reinterpret_cast<const kng_dp_record *>(h->h_items);
+    *records = nullptr;
     *n_items = 0;
     if (n_lost) *n_lost = 0;
     uint32_t found = 0, lost = 0;
     const int rc = land_points(h, h->max_found, &found, &lost);
     if (rc != KNG_OK) return rc;
+    *records = reinterpret_cast<const kng_dp_record *>(h->view ? h->view : h->h_items);
     *n_items = found;
     if (n_lost) *n_lost = lost;
     return KNG_OK;

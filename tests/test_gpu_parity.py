@@ -362,6 +362,48 @@ def test_every_walk_kernel_vs_oracle(kng, orc, share, rp, dsplit, use_asm):
     eng.close()
 
 
+@pytest.mark.parametrize("use_asm", [1, 0])
+def test_dp_ring_delivers_the_same_records(kng, orc, use_asm):
+    """Option "dp_ring": the kernel writes its DP records straight into pinned, device-mapped host memory (north_star:
+    "compaction of distinguished points into a pinned host ring buffer") instead of a device buffer that land_points
+    copies.  Same multiset as the oracle over three launches (both buffers of the ring get used), through kng_drain and
+    through the zero-copy view; a buffer that is too small loses the same number of points either way."""
+    grid, rp = (4, 8), 72
+    n = grid[0] * grid[1] * 128
+    x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=4242)
+    jd, jx, jy, _ = orc.jump_table(rp)
+    mask = orc.dp_mask(3)
+    key = lambda r: (int(r["kidx"]), tuple(int(v) for v in r["x"]), tuple(int(v) for v in r["d"]))  # noqa: E731
+    ox, oy = x.copy(), y.copy()
+    od = ints_to_array(device_distances(true_d, wild_offset), 2)
+    eng = kng.GPUEngine(grid[0], grid[1], 0, 1 << 16, asm=use_asm, dp_ring=1)
+    assert eng.get_option("dp_ring") == 1
+    eng.SetParams(mask, jd, jx, jy)
+    eng.SetWildOffset(wild_offset)
+    eng.SetKangaroos(x, y, ints_to_array(true_d))
+    for _ in range(3):
+        eng.callKernel()
+        eng.wait()
+        got = eng.drain(raw=True)
+        want, _total = orc.walk(ox, oy, od, 64, jd, jx, jy, mask, dp_cap=1 << 20)
+        assert len(got) > 1000 and sorted(map(key, got)) == sorted(map(key, want))
+    eng.close()
+    # overflow: 512 slots for ~30 000 points
+    small = kng.GPUEngine(grid[0], grid[1], 0, 512, asm=use_asm, dp_ring=1)
+    small.SetParams(mask, jd, jx, jy)
+    small.SetWildOffset(wild_offset)
+    small.SetKangaroos(x, y, ints_to_array(true_d))
+    small.callKernel()
+    small.wait()
+    got = small.drain(raw=True)
+    ox, oy = x.copy(), y.copy()
+    od = ints_to_array(device_distances(true_d, wild_offset), 2)
+    want, total = orc.walk(ox, oy, od, 64, jd, jx, jy, mask, dp_cap=1 << 20)
+    assert len(got) == 512 and small.lastLost == total - 512
+    assert set(map(key, got)) <= set(map(key, want))
+    small.close()
+
+
 @pytest.mark.parametrize("dsplit", [1, 0])
 def test_bench_config_total_parity(kng, orc, dsplit):
     """BASELINE.md 3's gate taken literally, at the bench configuration (80-bit range, grid 512x128 = 2^23 kangaroos,
@@ -511,6 +553,23 @@ def test_reference_program_solves_in_txt_on_our_engine(tmp_path):
     cfg = tmp_path / "in.txt"
     cfg.write_text("0\n%X\n%s\n" % (IN_TXT_RANGE_END, IN_TXT_PUBKEY))
     out = subprocess.run([exe, "-t", "0", "-gpu", "-g", "16,128", str(cfg)], capture_output=True, text=True, timeout=300)
+    assert "Priv: 0x%X" % IN_TXT_ANSWER in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
+
+
+def test_reference_program_drives_two_engines_concurrently(tmp_path):
+    """The reference's own thread-per-engine path over the boundary (Kangaroo.cpp:1041-1047: one _SolveKeyGPU pthread per
+    -gpuId entry): `-gpuId 0,0` makes the unmodified program create TWO GPUEngine instances and drive them from two
+    host threads at once, feeding one HashTable.  SURVEY 8(b): distinct instances from distinct threads must work
+    (every entry point selects its own device, nothing is global)."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "kangaroo_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/kangaroo_hip not built (needs /root/reference at build time)")
+    cfg = tmp_path / "in.txt"
+    cfg.write_text("0\n%X\n%s\n" % (IN_TXT_RANGE_END, IN_TXT_PUBKEY))
+    out = subprocess.run([exe, "-t", "0", "-gpu", "-gpuId", "0,0", "-g", "32,128,32,128", str(cfg)], capture_output=True, text=True, timeout=300)
+    assert out.stdout.count("GPU: GPU #0") == 2, out.stdout[-2000:]  # two engines were created
     assert "Priv: 0x%X" % IN_TXT_ANSWER in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
 
 

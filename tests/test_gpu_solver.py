@@ -365,3 +365,84 @@ def test_restore_into_a_different_number_of_gpus(sv, tmp_path, orc):
 
 
 N_ORDER_ = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141
+
+
+def test_configs4_save_restore_at_the_default_herd(sv, orc, tmp_path):
+    """BASELINE configs[4] at its real size on one GPU: 125-bit range (the maximum), the DEFAULT grid
+    = 2^23 kangaroos, whose kangaroo section is 96 B x 2^23 = 805 MB (Backup.cpp:525-546: 6.4 GB at 8 GPUs).
+      * kngs_save with kangaroos: seconds and GB/s reported (gpurun_out/r03_configs4_default_herd.txt);
+      * the reference's own -winfo reads the count, -wcheck accepts the file;
+      * kngs_load into a NEW solver, exactly one launch, save again: ALL 2^23 (x, y, d) equal the oracle walking the
+        SAVED herd 64 jumps (total parity: nothing lost or reordered through device -> file -> device)."""
+    import time
+
+    import kangaroo_amd as k
+    import kangaroo_amd.hostlib as hl
+
+    rp = 125
+    key = (1 << 124) + 0x1234567890ABCDEF1234567890ABCDE
+    kxy = hl.pubkey(key)[1:]
+    gx, gy = k.default_grid(0)
+    n = gx * gy * 128
+    f1, f2 = str(tmp_path / "c4a.work"), str(tmp_path / "c4b.work")
+    lines = []
+
+    # DP 20 instead of the suggestion (33+ at this range and herd: no point in two launches): ~1000 distinguished points
+    # for the reference's -wcheck to re-derive
+    a = sv.Solver(0, (1 << rp) - 1, kxy, grid=(gx, gy), dp=20, seed=0xC4, max_launches=2)
+    a.start()
+    assert a.wait(300) == 2
+    t0 = time.time()
+    a.save(f1, True)
+    t_save = time.time() - t0
+    sa = a.stats()
+    a.stop()
+    a.close()
+    size = os.path.getsize(f1)
+    assert size >= 96 * n
+    lines.append(f"herd {gx}x{gy}x128 = {n} kangaroos, range 2^{rp}, dp {sa['dp']}: file {size / 1e6:.1f} MB (kangaroo section {96 * n / 1e6:.1f} MB)")
+    lines.append(f"kngs_save  with kangaroos: {t_save:.3f} s = {size / t_save / 1e9:.2f} GB/s (device -> pinned staging -> file, atomic rename)")
+
+    if os.path.exists(REF_CPU):
+        info = subprocess.run([REF_CPU, "-winfo", f1], capture_output=True, text=True, timeout=300).stdout
+        assert f"Kangaroos : {n} " in info, info
+        chk = subprocess.run([REF_CPU, "-t", "8", "-wcheck", f1], capture_output=True, text=True, timeout=600).stdout
+        assert "[100.000% OK]" in chk, chk[-1500:]  # Check.cpp:398: every stored DP re-derived from (distance, type)
+        lines.append(f"reference -winfo: kangaroo count {n} ok; reference -wcheck: [100.000% OK] over {sa['dps']} distinguished points")
+
+    t0 = time.time()
+    h1, n1, (x1, y1, d1) = sv.read_workfile(f1, None)
+    lines.append(f"kngw read  (host, {n1} kangaroos): {time.time() - t0:.3f} s")
+    assert n1 == n and h1["count"] == sa["jumps"] == 2 * n * 64
+
+    b = sv.Solver(0, (1 << rp) - 1, kxy, grid=(gx, gy), dp=-1, seed=0xDEAD, max_launches=1)
+    t0 = time.time()
+    b.load(f1)
+    b.prepare()
+    t_load = time.time() - t0
+    lines.append(f"kngs_load + prepare (file -> pinned staging -> device): {t_load:.3f} s = {size / t_load / 1e9:.2f} GB/s")
+    b.start()
+    assert b.wait(300) == 2
+    b.save(f2, True)
+    sb = b.stats()
+    b.stop()
+    b.close()
+    assert sb["jumps"] == sa["jumps"] + n * 64 and sb["herd_loaded"] == n and sb["herd_created"] == 0
+    _h2, n2, (x2, y2, d2) = sv.read_workfile(f2, None)
+    assert n2 == n
+
+    woff = ((1 << rp) - 1) >> 1
+    jd, jx, jy, _ = orc.jump_table(rp)
+    od = hl.to_device_distances(d1, woff)
+    ox, oy = x1.copy(), y1.copy()
+    t0 = time.time()
+    orc.walk_parallel(ox, oy, od, 64, jd, jx, jy, hl.dp_mask(sb["dp"]))
+    lines.append(f"oracle walk of the saved herd (64 jumps, thread pool): {time.time() - t0:.1f} s")
+    assert sa["dps"] > 200 and sb["same_herd"] == 0  # no same-herd replacement happened: every kangaroo must match
+    assert np.array_equal(x2, ox) and np.array_equal(y2, oy)
+    assert np.array_equal(hl.to_device_distances(d2, woff), od)
+    lines.append(f"restored herd after one launch == oracle walk of the saved herd: ALL {n} (x, y, d) bit-exact")
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "r03_configs4_default_herd.txt"), "w") as f:
+        f.write("# tests/test_gpu_solver.py::test_configs4_save_restore_at_the_default_herd (BASELINE configs[4] on one MI355X)\n" + "\n".join(lines) + "\n")

@@ -11,8 +11,9 @@ one move per word instead of the compiler's copies.
 
 Exact-path protocol.  The short forms (single-chain fold, two-limb borrow fix-up, low-word distance add) flag the lanes
 for which they are not exact in an SGPR mask.  When any lane of the wave is flagged, the iteration is abandoned BEFORE
-anything is stored: the statement returns with k = that iteration, `inv`/`acc` untouched, and the C++ caller runs this
-one iteration with the generic code (walk_one in kng_engine.hip), then re-enters at k + 1.
+anything is stored: the statement returns with k = that iteration and `inv` untouched (`acc` is undefined: the caller
+re-reads it from the product plane, S[slot(k-1)], or takes 1 for k = 0), and the C++ caller runs this one iteration with
+the generic code (walk_core in kng_engine.hip), then re-enters at k + 1.
 
 Interface (see KNG_WALK_ASM_LOOP at the end of the generated header):
     in/out  inv[8], acc[8]   32-bit limbs of the running inverse / running prefix product
@@ -48,7 +49,7 @@ class Loop:
         A = self.A = Asm()
         # ---- operands (compiler-allocated)
         self.INV = [A.operand("v", f"%{i}") for i in range(8)]
-        self.ACC = [A.operand("v", f"%{8 + i}") for i in range(8)]
+        self.ACCop = [A.operand("v", f"%{8 + i}") for i in range(8)]
         self.k = A.operand("s", "%16")
         self.voff = A.operand("v", "%17")
         self.args = A.operand("s", "%18", 2)
@@ -69,9 +70,13 @@ class Loop:
         q = lambda n: A.vt(n, 4, pinned=True)  # noqa: E731
         self.CX, self.CY = [q("cx0"), q("cx1")], [q("cy0"), q("cy1")]
         self.NX, self.NY = [q("nx0"), q("nx1")], [q("ny0"), q("ny1")]
-        self.NB, self.NNB = [q("nb0"), q("nb1")], [q("nnb0"), q("nnb1")]
+        self.NB = [q("nb0"), q("nb1")]  # neighbour product; reloaded in place for the next kangaroo once P1 has read it
+        # running prefix product: lives in two quads inside the statement (it is stored every iteration) and is updated
+        # IN PLACE by P6 -- after an exact-path exit its old value is re-read from the product plane (S[slot(k-1)], or 1)
+        self.ACCq = [q("acc0"), q("acc1")]
         self.CD, self.ND = q("cd"), q("nd")  # distance: (lo0, lo1, hi0, hi1); DSPLIT streams only the low pair
         self.F = kfield.Field(A, self.k977, self.rare)
+        self.F.elide_first_carry = os.environ.get("KASM_ELIDE", "0") == "1"
 
     @staticmethod
     def limbs(quads):
@@ -105,6 +110,8 @@ class Loop:
         A.s_mov_b32(self.k977, 977)
         A.v_mov_b32(self.v977, 977)
         A.s_mov_b64(self.rare, 0)
+        for d, s_ in zip(self.limbs(self.ACCq), self.ACCop):
+            A.v_mov_b32(d, s_)
         A.s_waitcnt(lgkmcnt=0, regs=[self.planes, self.dpblk])
         voff8 = A.v("voff8e")
         A.v_lshrrev_b32(voff8, 1, self.voff)
@@ -147,7 +154,6 @@ class Loop:
         self.load_fe(self.NX, voffn, "x01", "x23", True)
         self.load_fe(self.NY, voffn, "y01", "y23", True)
         self.load_d(self.ND, voffn8)
-        self.load_fe(self.NNB, voffnn, "s01", "s23", False)
         # jump table entry j = x & 31
         cx, cy = self.limbs(self.CX), self.limbs(self.CY)
         jidx, laddr = A.v("jidx"), A.v("laddr")
@@ -167,12 +173,15 @@ class Loop:
         nb = self.limbs(self.NB)
         # P1: invk = inv * nb ; dx, dy ; P2: inv' = inv * dx
         IK = kfield.fe_mul(F, self.INV, nb, tag="p1")
+        # the product behind the next kangaroo, straight into the registers P1 has just read (write-after-read
+        # dependencies place the loads behind P1's last multiply): no second register set, no moves
+        self.load_fe(self.NB, voffnn, "s01", "s23", False)
         dx = kfield.fe_sub(F, cx, jx, tag="dx", k977_v=self.v977)
         dy = kfield.fe_sub(F, cy, jy, tag="dy", k977_v=self.v977)
         INVn = kfield.fe_mul(F, self.INV, dx, tag="p2")
         # P3: s = dy * invk ; P4: s^2
         S = kfield.fe_mul(F, dy, IK, tag="p3")
-        SQ = kfield.fe_mul(F, S, S, tag="p4")
+        SQ = kfield.fe_sqr(F, S, tag="p4")
         # rx = s^2 - jx - cx ; ry = (cx - rx) * s - cy
         r0 = kfield.fe_sub(F, SQ, jx, tag="ra", k977_v=self.v977)
         RXq = [A.vt("rx0", 4), A.vt("rx1", 4)]
@@ -201,8 +210,8 @@ class Loop:
         A.ds_read2_b64(JX2[1], laddr2, 64, 96)
         A.s_waitcnt(lgkmcnt=0, regs=JX2)
         dx2 = kfield.fe_sub(F, RX, self.limbs(JX2), tag="dx2", k977_v=self.v977)
-        ACCq = [A.vt("accn0", 4), A.vt("accn1", 4)]
-        ACCn = kfield.fe_mul(F, self.ACC, dx2, out=self.limbs(ACCq), tag="p6")
+        ACCq = self.ACCq
+        ACCn = kfield.fe_mul(F, self.limbs(ACCq), dx2, out=self.limbs(ACCq), tag="p6")  # in place (write-after-read ordered)
         # distinguished point?  (x.limb3 & dpMask) == 0, GPUCompute.h:96
         t1, t2 = A.v("dpt1"), A.v("dpt2")
         A.v_and_b32(t1, self.dp_mask_lo, RX[6])
@@ -271,13 +280,11 @@ class Loop:
         A.label(L_nodp)
         A.cur.schedule = False
         n_after = 7 if self.dsplit else 8  # stores of this iteration issued behind the prefetch loads (x, y: 4; d: 1 or 2; products: 2)
-        A.s_waitcnt(vmcnt=n_after, regs=self.NX + self.NY + [self.ND.sub(0, 2)] + ([] if self.dsplit else [self.ND.sub(2, 2)]) + self.NNB)
+        A.s_waitcnt(vmcnt=n_after, regs=self.NX + self.NY + [self.ND.sub(0, 2)] + ([] if self.dsplit else [self.ND.sub(2, 2)]) + self.NB)
         A.block("commit")
         for d, s_ in zip(self.INV, INVn):
             A.v_mov_b32(d, s_)
-        for d, s_ in zip(self.ACC, ACCn):
-            A.v_mov_b32(d, s_)
-        for dq, sq in ((self.CX, self.NX), (self.CY, self.NY), (self.NB, self.NNB)):
+        for dq, sq in ((self.CX, self.NX), (self.CY, self.NY)):
             for d, s_ in zip(self.limbs(dq), self.limbs(sq)):
                 A.v_mov_b32(d, s_)
         for i in range(2 if self.dsplit else 4):
@@ -301,6 +308,8 @@ class Loop:
         A.raw("; cold path")
         A.label(L_exit)
         A.cur.schedule = False
+        for d, s_ in zip(self.ACCop, self.limbs(self.ACCq)):
+            A.v_mov_b32(d, s_)  # (undefined after an exact-path exit: P6 may have started to overwrite it)
         A.s_waitcnt(vmcnt=0, lgkmcnt=0)
         A.s_nop(1)
         return self

@@ -29,6 +29,9 @@ class Field:
         """k977_s: SGPR holding 977; rare: SGPR pair that collects "short form not exact" lane masks"""
         self.A, self.k977, self.rare = A, k977_s, rare
         self.n = 0
+        # a column's first multiply-add starts from a carry-in below 2^36 and overflows 64 bits only when its product is
+        # within 2^36 of 2^64 (~2^-28): flag it for the exact path instead of counting it with a v_addc
+        self.elide_first_carry = False
 
     def uid(self, stem):
         self.n += 1
@@ -58,9 +61,13 @@ def comba(F: Field, a, b, tag="m"):
         can_overflow = 0 < k < 14
         carries = []
         for n_, (i, j) in enumerate(terms):
-            c = A.st(F.uid("c"), 2) if can_overflow else DUMMY
+            # column 1 starts from X0 < 2^32: a*b + X0 <= 2^64 - 2^32, its first product cannot overflow at all
+            first_safe = n_ == 0 and (k == 1 or F.elide_first_carry)
+            c = A.st(F.uid("c"), 2) if can_overflow and not (n_ == 0 and k == 1) else DUMMY
             A.v_mad_u64_u32(acc, c, a[i], b[j], addend if n_ == 0 else acc, comment=f"a{i}*b{j}")
-            if can_overflow:
+            if can_overflow and n_ == 0 and k > 1 and F.elide_first_carry:
+                A.s_or_accum(F.rare, c)
+            elif can_overflow and not first_safe:
                 carries.append(c)
         if carries:
             nhi = accs[k + 1].hi
@@ -69,6 +76,74 @@ def comba(F: Field, a, b, tag="m"):
     # column 13's low word (w13) still sits in its temporary; column 14 is PW[7] = (w14, w15)
     # (the k == 14 iteration above packed w13 into PW[6].hi)
     return PW
+
+
+def comba_sqr(F: Field, a, tag="q"):
+    """a: 8 Regs.  a^2 = 2*O + D with O = sum_{i<j} a_i a_j 2^(32(i+j)) (28 MADs through the same column machinery) and
+    D = sum a_i^2 2^(64 i), whose eight 64-bit squares do not overlap (8 MADs, no carries); the doubling is one
+    v_alignbit_b32 per limb feeding the final 16-limb carry chain, which writes the (w[2m], w[2m+1]) pairs directly.
+    Same 512-bit integer as comba(a, a): 36 instead of 64 multiplies (kng_mul32.h sqr_wide32 is the round-1 form)."""
+    A = F.A
+    PW = [A.vt(F.uid(f"{tag}pw"), 2) for _ in range(8)]
+    D = [A.vt(F.uid(f"{tag}d"), 2) for _ in range(8)]
+    for m in range(8):
+        A.v_mad_u64_u32(D[m], DUMMY, a[m], a[m], 0, comment=f"a{m}^2")
+    accs = {k: A.vt(F.uid(f"{tag}o"), 2) for k in range(1, 14)}
+    o = [None] * 16  # o[k] = limb k of O
+    hi_last = None
+    for k in range(1, 14):
+        acc = accs[k]
+        terms = [(i, k - i) for i in range(max(0, k - 7), min(7, k) + 1) if i < k - i]
+        if k == 1:
+            addend = 0
+        else:
+            prev = accs[k - 1]
+            A.v_mov_b32(acc.lo, prev.hi, comment=f"col {k} <- carry word of col {k - 1}")
+            if k <= 3:
+                A.v_mov_b32(acc.hi, 0)  # columns 1 and 2 (one product each, small carry-in) cannot overflow 64 bits
+            addend = acc
+        can_overflow = k >= 3
+        carries = []
+        for n_, (i, j) in enumerate(terms):
+            c = A.st(F.uid("c"), 2) if can_overflow else DUMMY
+            A.v_mad_u64_u32(acc, c, a[i], a[j], addend if n_ == 0 else acc, comment=f"a{i}*a{j}")
+            if can_overflow and n_ == 0 and F.elide_first_carry:
+                A.s_or_accum(F.rare, c)
+            elif can_overflow:
+                carries.append(c)
+        if can_overflow:
+            if k < 13:
+                nhi = accs[k + 1].hi
+            else:
+                nhi = hi_last = A.v(F.uid(f"{tag}o15"))
+            if not carries:
+                A.v_mov_b32(nhi, 0)
+            for n_, c in enumerate(carries):
+                A.v_addc_co_u32(nhi, DUMMY, 0, 0 if n_ == 0 else nhi, c)
+        o[k] = acc.lo
+    o[14], o[15] = accs[13].hi, hi_last
+    # w = 2*O + D
+    C = A.st(F.uid("qc"), 2)
+    A.v_mov_b32(PW[0].lo, D[0].lo, comment="w0 = a0^2 low (O has no limb 0)")
+    for k in range(1, 16):
+        dbl = A.v(F.uid(f"{tag}dbl"))
+        if k == 1:
+            A.v_lshlrev_b32(dbl, 1, o[1])
+        else:
+            A.v_alignbit_b32(dbl, o[k], o[k - 1], 31, comment=f"(2*O) limb {k}")
+        d_k = D[k // 2][k % 2]
+        w_k = PW[k // 2][k % 2]
+        if k == 1:
+            A.v_add_co_u32(w_k, C, dbl, d_k)
+        elif k < 15:
+            A.v_addc_co_u32(w_k, C, dbl, d_k, C)
+        else:
+            A.v_addc_co_u32(w_k, DUMMY, dbl, d_k, C)  # a^2 < 2^512
+    return PW
+
+
+def fe_sqr(F: Field, a, out=None, tag="q"):
+    return fold(F, comba_sqr(F, a, tag), out, tag)
 
 
 def fold(F: Field, PW, out=None, tag="f"):
@@ -133,14 +208,16 @@ def fe_sub(F: Field, x, y, out=None, tag="s", k977_v=None):
     A.v_subb_co_u32(t[1], B, x[1], y[1], B)
     for i in range(2, 8):
         A.v_subb_co_u32(out[i], B, x[i], y[i], B)
-    # borrow: subtract 2^256 - p = 2^32 + 977
-    q0, q1 = A.v(F.uid(f"{tag}q")), A.v(F.uid(f"{tag}q"))
+    # borrow: subtract 2^256 - p = 2^32 + 977.  The 2^32 goes in as the BORROW-IN of limb 1 (the lane mask B itself);
+    # the borrow out of limb 0 (t0 < 977, once in 2^22 borrowing subtractions) and the one out of limb 1 both mean
+    # "exact path" -- so no second select and no second chain link.
+    q0 = A.v(F.uid(f"{tag}q"))
     A.v_cndmask_b32(q0, 0, k977_v, B)
-    A.v_cndmask_b32(q1, 0, 1, B)
-    D = A.st(F.uid("sd"), 2)
+    D, E = A.st(F.uid("sd"), 2), A.st(F.uid("se"), 2)
     A.v_sub_co_u32(out[0], D, t[0], q0)
-    A.v_subb_co_u32(out[1], D, t[1], q1, D)
-    A.s_or_accum(F.rare, D)  # the borrow leaves the low 64 bits once in 2^32: exact path elsewhere
+    A.v_subb_co_u32(out[1], E, t[1], 0, B)
+    A.s_or_accum(F.rare, D)
+    A.s_or_accum(F.rare, E)
     return out
 
 

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--dsplit", type=int, default=-1, help="-1 auto / 0 / 1: low-word streaming of the distances")
     ap.add_argument("--jd-bits", type=int, default=40, help="size of the synthetic jump distances: 54+ makes both distance words stream (the non-dsplit kernels)")
     ap.add_argument("--lanes", default="", help="explicit lane counts (ragged groups); overrides --groups")
+    ap.add_argument("--dp-ring", default="0", help="comma list of 0/1: DP records into a device buffer + copy / straight into pinned host memory")
     ap.add_argument("--asm", default="1", help="comma list of 0/1: compiler-scheduled loop / scheduled asm loop")
     a = ap.parse_args()
     gx, gy = (int(v) for v in a.grid.split(","))
@@ -43,11 +44,11 @@ def main():
     mask = (~((1 << (64 - a.dp)) - 1)) & ((1 << 64) - 1) if a.dp else 0
     print(f"herd {n} = 2^{np.log2(n):.2f} kangaroos, dp {a.dp}", flush=True)
     glist = [("lanes", int(v)) for v in a.lanes.split(",")] if a.lanes else [("group", int(v)) for v in a.groups.split(",")]
-    for (gk, g), b, sh, use_asm in ((g, b, sh, am) for g in glist
-                                    for b in (int(v) for v in a.blocks.split(",")) for sh in (int(v) for v in a.shares.split(","))
-                                    for am in (int(v) for v in a.asm.split(","))):
+    for (gk, g), b, sh, use_asm, ring in ((g, b, sh, am, rg) for g in glist
+                                          for b in (int(v) for v in a.blocks.split(",")) for sh in (int(v) for v in a.shares.split(","))
+                                          for am in (int(v) for v in a.asm.split(",")) for rg in (int(v) for v in a.dp_ring.split(","))):
         if True:
-            eng = k.GPUEngine(gx, gy, 0, 1 << 17, block=b, share=sh, asm=use_asm, **({"dsplit": a.dsplit} if a.dsplit >= 0 else {}), **{gk: g})
+            eng = k.GPUEngine(gx, gy, 0, max(1 << 17, 2 * ((n * 64) >> a.dp)) if a.dp else 1 << 17, block=b, share=sh, asm=use_asm, dp_ring=ring, **({"dsplit": a.dsplit} if a.dsplit >= 0 else {}), **{gk: g})
             eng.SetParams(mask, jd, jx, jy)
             eng.SetKangaroos(x, y, d)
             eng.callKernel()
@@ -63,7 +64,7 @@ def main():
             wall = time.time() - t0
             kms = float(np.mean(ms))
             rate = n * 64 / (kms * 1e-3) / 1e6
-            print(f"asm {use_asm} share {sh} group {eng.get_option('group'):4d} block {b:4d} lanes {eng.get_option('lanes'):7d} waves/CU {eng.get_option('waves_per_cu'):3d}: "
+            print(f"asm {use_asm} ring {ring} share {sh} group {eng.get_option('group'):4d} block {b:4d} lanes {eng.get_option('lanes'):7d} waves/CU {eng.get_option('waves_per_cu'):3d}: "
                   f"kernel {kms:9.2f} ms  {rate:10.1f} MK/s  ({rate * 160 / 1e6:6.3f} TB/s @160B)  wall/launch {wall / a.launches * 1e3:8.2f} ms  DPs {nd}",
                   flush=True)
             eng.close()
