@@ -149,6 +149,10 @@ int kng_last_kernel_ms(const kng_engine *h, float *ms);
  *   "dsplit" -1 (default): stream only the low word of the 128-bit distances through HBM when every jump
  *            distance given to kng_set_params is below 2^50 (the high word is then updated on the rare carry);
  *            0 = never, 1 = whenever the table allows it (all high words zero).  Reads back 0/1 = in effect.
+ *   "asm"    1 (default): the per-kangaroo loop runs as one scheduled asm statement (kng_walk_asm.h); 0 = the
+ *            compiler-scheduled loop (also what herds beyond 2^28 kangaroos get).  Same results.
+ *   "dp_ring" 1 (default): the kernel writes its DP records straight into pinned, device-mapped host memory, one buffer
+ *            per launch slot, the count landing last; 0 = device buffer + copy at drain time (rounds 1-2)
  *   "steps"  jumps per launch (default KNG_NB_RUN; only tests change it)
  * kng_get_option reads them back (also "lanes", "waves_per_cu"). */
 int kng_set_option(kng_engine *h, const char *key, int64_t value);

@@ -604,7 +604,7 @@ struct kng_engine {
     // option "dp_ring": the kernel writes its DP records straight into pinned, device-mapped host memory (one buffer per
     // launch slot; the counter stays in device memory -- an atomic per DP-bearing wave-step across PCIe would stall the
     // walk -- and lands last, stream-ordered behind the kernel).  No second hop, no host-synchronous copy in land_points.
-    int dp_ring = 0;
+    int dp_ring = 1; // default since round 3: kernel time -0.8 % at DP 14, -0.4 % at DP 11, no host-synchronous copy (profiles/r03_ab_dp_ring.txt)
     DpRecord *ring[2] = {nullptr, nullptr};     // host view
     DpRecord *ring_dev[2] = {nullptr, nullptr}; // device view of the same memory
     const DpRecord *view = nullptr;             // where the records of the last drained launch are
@@ -750,6 +750,12 @@ int kng_create(int dev, int grid_x, int grid_y, uint32_t max_found, kng_engine *
     }
     if ((e = hipHostMalloc((void **)&h->h_items, (size_t)max_found * sizeof(DpRecord), hipHostMallocDefault)) != hipSuccess)
         return bail(fail(KNG_E_ALLOC, "pinned dp items: %s", hipGetErrorString(e)));
+    for (int s = 0; s < 2; s++) { // the DP ring: pinned host memory the kernel writes directly (option "dp_ring")
+        if ((e = hipHostMalloc((void **)&h->ring[s], (size_t)max_found * sizeof(DpRecord), hipHostMallocMapped | hipHostMallocPortable)) != hipSuccess)
+            return bail(fail(KNG_E_ALLOC, "pinned DP ring (%zu bytes): %s", (size_t)max_found * sizeof(DpRecord), hipGetErrorString(e)));
+        if ((e = hipHostGetDevicePointer((void **)&h->ring_dev[s], h->ring[s], 0)) != hipSuccess)
+            return bail(fail(KNG_E_HIP, "device view of the DP ring: %s", hipGetErrorString(e)));
+    }
     h->stage_kang = h->n < (1u << 16) ? (size_t)h->n : (size_t)(1u << 16);
     if ((e = hipHostMalloc((void **)&h->h_stage, 6 * h->stage_kang * sizeof(v16), hipHostMallocDefault)) != hipSuccess)
         return bail(fail(KNG_E_ALLOC, "pinned staging: %s", hipGetErrorString(e)));

@@ -362,12 +362,14 @@ def test_every_walk_kernel_vs_oracle(kng, orc, share, rp, dsplit, use_asm):
     eng.close()
 
 
+@pytest.mark.parametrize("ring", [1, 0])
 @pytest.mark.parametrize("use_asm", [1, 0])
-def test_dp_ring_delivers_the_same_records(kng, orc, use_asm):
+def test_dp_ring_delivers_the_same_records(kng, orc, use_asm, ring):
     """Option "dp_ring": the kernel writes its DP records straight into pinned, device-mapped host memory (north_star:
     "compaction of distinguished points into a pinned host ring buffer") instead of a device buffer that land_points
     copies.  Same multiset as the oracle over three launches (both buffers of the ring get used), through kng_drain and
-    through the zero-copy view; a buffer that is too small loses the same number of points either way."""
+    through the zero-copy view; a buffer that is too small loses the same number of points either way.  ring = 0 is the
+    device-buffer-and-copy path of rounds 1-2 (still an option)."""
     grid, rp = (4, 8), 72
     n = grid[0] * grid[1] * 128
     x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=4242)
@@ -376,8 +378,8 @@ def test_dp_ring_delivers_the_same_records(kng, orc, use_asm):
     key = lambda r: (int(r["kidx"]), tuple(int(v) for v in r["x"]), tuple(int(v) for v in r["d"]))  # noqa: E731
     ox, oy = x.copy(), y.copy()
     od = ints_to_array(device_distances(true_d, wild_offset), 2)
-    eng = kng.GPUEngine(grid[0], grid[1], 0, 1 << 16, asm=use_asm, dp_ring=1)
-    assert eng.get_option("dp_ring") == 1
+    eng = kng.GPUEngine(grid[0], grid[1], 0, 1 << 16, asm=use_asm, dp_ring=ring)
+    assert eng.get_option("dp_ring") == ring
     eng.SetParams(mask, jd, jx, jy)
     eng.SetWildOffset(wild_offset)
     eng.SetKangaroos(x, y, ints_to_array(true_d))
@@ -389,7 +391,7 @@ def test_dp_ring_delivers_the_same_records(kng, orc, use_asm):
         assert len(got) > 1000 and sorted(map(key, got)) == sorted(map(key, want))
     eng.close()
     # overflow: 512 slots for ~30 000 points
-    small = kng.GPUEngine(grid[0], grid[1], 0, 512, asm=use_asm, dp_ring=1)
+    small = kng.GPUEngine(grid[0], grid[1], 0, 512, asm=use_asm, dp_ring=ring)
     small.SetParams(mask, jd, jx, jy)
     small.SetWildOffset(wild_offset)
     small.SetKangaroos(x, y, ints_to_array(true_d))

@@ -77,6 +77,7 @@ class Loop:
         self.CD, self.ND = q("cd"), q("nd")  # distance: (lo0, lo1, hi0, hi1); DSPLIT streams only the low pair
         self.F = kfield.Field(A, self.k977, self.rare)
         self.F.elide_first_carry = os.environ.get("KASM_ELIDE", "0") == "1"
+        self.unroll = int(os.environ.get("KASM_UNROLL", "2"))
 
     @staticmethod
     def limbs(quads):
@@ -99,9 +100,16 @@ class Loop:
             A.v_mov_b32(r, 1 if i == 0 else 0)
 
     def build(self):
-        A, F = self.A, self.F
-        L_loop, L_exit, L_rare = ".Lkw_loop_%=", ".Lkw_exit_%=", ".Lkw_rare_%="
-        L_nb1, L_nbd, L_dp, L_nodp, L_fix = ".Lkw_nb1_%=", ".Lkw_nbd_%=", ".Lkw_dp_%=", ".Lkw_nodp_%=", ".Lkw_fix_%="
+        """entry; loop { iteration A (state set 0 -> set 1); iteration B (set 1 -> set 0) }; exits.  With UNROLL = 1 only
+        iteration A exists and its tail moves set 1 back to set 0 (27 moves per kangaroo-jump)."""
+        A = self.A
+        unroll = self.unroll
+        L_exit, L_nb1, L_nbd = ".Lkw_exit_%=", ".Lkw_nb1_%=", ".Lkw_nbd_%="
+        # ---- the two state sets: x, y, distance, running inverse, plane offset
+        q = lambda n: A.vt(n, 4, pinned=True)  # noqa: E731
+        set0 = dict(X=self.CX, Y=self.CY, D=self.CD, INV=self.INV, voff=self.voff)
+        set1 = dict(X=self.NX, Y=self.NY, D=self.ND, voff=A.v("voff1", pinned=True),
+                    INV=[r for qd in (q("inv1a"), q("inv1b")) for r in qd.regs] if unroll == 2 else None)
         # ================= entry (unscheduled) =================
         A.cur.schedule = False
         A.s_nop(4)  # operands may come fresh from a VALU (readfirstlane) : VALU-written SGPR -> SMEM/VMEM
@@ -134,10 +142,34 @@ class Loop:
         A.cur.schedule = False
         A.s_waitcnt(vmcnt=0, regs=self.CX + self.CY + [self.CD] + self.NB)
         # ================= loop =================
-        A.label(L_loop)
+        L_loop = ".Lkw_loop_%="
+        if unroll == 1:
+            self.iteration("a", set0, set1, L_loop, L_loop, L_exit, copy_back=True)
+        else:
+            L_b = ".Lkw_loopb_%="
+            self.iteration("a", set0, set1, L_loop, L_b, L_exit)
+            self.iteration("b", set1, set0, L_b, L_loop, L_exit)
+        # ================= exit =================
+        A.label(L_exit)
+        A.cur.schedule = False
+        for d, s_ in zip(self.ACCop, self.limbs(self.ACCq)):
+            A.v_mov_b32(d, s_)  # (undefined after an exact-path exit: P6 may have started to overwrite it)
+        A.s_waitcnt(vmcnt=0, lgkmcnt=0)
+        A.s_nop(1)
+        return self
+
+    def iteration(self, tag, cur, nxt, L_top, L_next, L_exit, copy_back=False):
+        """one kangaroo: state in `cur`, the next kangaroo's state is prefetched into (and the new running inverse written
+        to) `nxt`.  Falls out of the loop to L_exit when k reaches G or a lane needs the exact path."""
+        A, F = self.A, self.F
+        T = lambda n: f"{n}_{tag}"  # noqa: E731
+        L_rare, L_nodp, L_fix = f".Lkw_rare{tag}_%=", f".Lkw_nodp{tag}_%=", f".Lkw_fix{tag}_%="
+        CX, CY, CD, INV, voff = cur["X"], cur["Y"], cur["D"], cur["INV"], cur["voff"]
+        NX, NY, ND = nxt["X"], nxt["Y"], nxt["D"]
+        A.label(L_top)
         A.cur.schedule = False
         # clamped strides for the prefetch: slot(k+1) if it exists else slot(k); slot(k+2) likewise
-        s1, s2, k1, k2 = A.s("s1"), A.s("s2"), A.s("k1"), A.s("k2")
+        s1, s2, k1, k2 = A.s(T("s1")), A.s(T("s2")), A.s(T("k1")), A.s(T("k2"))
         A.s_add_u32(k1, self.k, 1)
         A.s_cmp("lt_u32", k1, self.G)
         A.s_cselect_b32(s1, self.stride, 0)
@@ -147,20 +179,21 @@ class Loop:
         A.s_mov_b64(self.rare, 0)
         # ---------------- block A: everything up to the exactness check (scheduled as one graph)
         A.block("A")
-        voffn, voffnn, voffn8 = A.v("voffn"), A.v("voffnn"), A.v("voffn8")
-        A.v_add_u32(voffn, s1, self.voff)
+        voffn = A.v(T("voffn")) if copy_back else nxt["voff"]
+        voffnn, voffn8 = A.v(T("voffnn")), A.v(T("voffn8"))
+        A.v_add_u32(voffn, s1, voff)
         A.v_add_u32(voffnn, s2, voffn)
         A.v_lshrrev_b32(voffn8, 1, voffn)
-        self.load_fe(self.NX, voffn, "x01", "x23", True)
-        self.load_fe(self.NY, voffn, "y01", "y23", True)
-        self.load_d(self.ND, voffn8)
+        self.load_fe(NX, voffn, "x01", "x23", True)
+        self.load_fe(NY, voffn, "y01", "y23", True)
+        self.load_d(ND, voffn8)
         # jump table entry j = x & 31
-        cx, cy = self.limbs(self.CX), self.limbs(self.CY)
-        jidx, laddr = A.v("jidx"), A.v("laddr")
+        cx, cy = self.limbs(CX), self.limbs(CY)
+        jidx, laddr = A.v(T("jidx")), A.v(T("laddr"))
         A.v_and_b32(jidx, 31, cx[0])
         A.v_lshl_add_u32(laddr, jidx, 3, self.ldstab)
-        JX, JY = [A.vt("jx0", 4), A.vt("jx1", 4)], [A.vt("jy0", 4), A.vt("jy1", 4)]
-        JD = A.vt("jd", 4)
+        JX, JY = [A.vt(T("jx0"), 4), A.vt(T("jx1"), 4)], [A.vt(T("jy0"), 4), A.vt(T("jy1"), 4)]
+        JD = A.vt(T("jd"), 4)
         A.ds_read2_b64(JX[0], laddr, 0, 32)
         A.ds_read2_b64(JX[1], laddr, 64, 96)
         A.ds_read2_b64(JY[0], laddr, 128, 160)
@@ -172,28 +205,28 @@ class Loop:
         jx, jy = self.limbs(JX), self.limbs(JY)
         nb = self.limbs(self.NB)
         # P1: invk = inv * nb ; dx, dy ; P2: inv' = inv * dx
-        IK = kfield.fe_mul(F, self.INV, nb, tag="p1")
+        IK = kfield.fe_mul(F, INV, nb, tag=T("p1"))
         # the product behind the next kangaroo, straight into the registers P1 has just read (write-after-read
         # dependencies place the loads behind P1's last multiply): no second register set, no moves
         self.load_fe(self.NB, voffnn, "s01", "s23", False)
-        dx = kfield.fe_sub(F, cx, jx, tag="dx", k977_v=self.v977)
-        dy = kfield.fe_sub(F, cy, jy, tag="dy", k977_v=self.v977)
-        INVn = kfield.fe_mul(F, self.INV, dx, tag="p2")
+        dx = kfield.fe_sub(F, cx, jx, tag=T("dx"), k977_v=self.v977)
+        dy = kfield.fe_sub(F, cy, jy, tag=T("dy"), k977_v=self.v977)
+        INVn = kfield.fe_mul(F, INV, dx, out=nxt["INV"], tag=T("p2"))
         # P3: s = dy * invk ; P4: s^2
-        S = kfield.fe_mul(F, dy, IK, tag="p3")
-        SQ = kfield.fe_sqr(F, S, tag="p4")
+        S = kfield.fe_mul(F, dy, IK, tag=T("p3"))
+        SQ = kfield.fe_sqr(F, S, tag=T("p4"))
         # rx = s^2 - jx - cx ; ry = (cx - rx) * s - cy
-        r0 = kfield.fe_sub(F, SQ, jx, tag="ra", k977_v=self.v977)
-        RXq = [A.vt("rx0", 4), A.vt("rx1", 4)]
-        RX = kfield.fe_sub(F, r0, cx, out=self.limbs(RXq), tag="rx", k977_v=self.v977)
-        T = kfield.fe_sub(F, cx, RX, tag="t", k977_v=self.v977)
-        Y0 = kfield.fe_mul(F, T, S, tag="p5")
-        RYq = [A.vt("ry0", 4), A.vt("ry1", 4)]
-        RY = kfield.fe_sub(F, Y0, cy, out=self.limbs(RYq), tag="ry", k977_v=self.v977)
+        r0 = kfield.fe_sub(F, SQ, jx, tag=T("ra"), k977_v=self.v977)
+        RXq = [A.vt(T("rx0"), 4), A.vt(T("rx1"), 4)]
+        RX = kfield.fe_sub(F, r0, cx, out=self.limbs(RXq), tag=T("rx"), k977_v=self.v977)
+        Tm = kfield.fe_sub(F, cx, RX, tag=T("t"), k977_v=self.v977)
+        Y0 = kfield.fe_mul(F, Tm, S, tag=T("p5"))
+        RYq = [A.vt(T("ry0"), 4), A.vt(T("ry1"), 4)]
+        RY = kfield.fe_sub(F, Y0, cy, out=self.limbs(RYq), tag=T("ry"), k977_v=self.v977)
         # d += jD  (raw 128-bit add, GPUMath.h:119-121)
-        DN = A.vt("dnew", 4)
-        cd = self.CD.regs
-        dc = A.st("dcar", 2)
+        DN = A.vt(T("dnew"), 4)
+        cd = CD.regs
+        dc = A.st(T("dcar"), 2)
         A.v_add_co_u32(DN[0], dc, cd[0], JD[0])
         A.v_addc_co_u32(DN[1], dc, cd[1], JD[1], dc)
         if self.dsplit:
@@ -202,22 +235,22 @@ class Loop:
             A.v_addc_co_u32(DN[2], dc, cd[2], JD[2], dc)
             A.v_addc_co_u32(DN[3], "vcc", cd[3], JD[3], dc)
         # prefix product of the next jump's dx: acc' = acc * (rx - J[rx & 31].x)
-        jidx2, laddr2 = A.v("jidx2"), A.v("laddr2")
+        jidx2, laddr2 = A.v(T("jidx2")), A.v(T("laddr2"))
         A.v_and_b32(jidx2, 31, RX[0])
         A.v_lshl_add_u32(laddr2, jidx2, 3, self.ldstab)
-        JX2 = [A.vt("jxn0", 4), A.vt("jxn1", 4)]
+        JX2 = [A.vt(T("jxn0"), 4), A.vt(T("jxn1"), 4)]
         A.ds_read2_b64(JX2[0], laddr2, 0, 32)
         A.ds_read2_b64(JX2[1], laddr2, 64, 96)
         A.s_waitcnt(lgkmcnt=0, regs=JX2)
-        dx2 = kfield.fe_sub(F, RX, self.limbs(JX2), tag="dx2", k977_v=self.v977)
+        dx2 = kfield.fe_sub(F, RX, self.limbs(JX2), tag=T("dx2"), k977_v=self.v977)
         ACCq = self.ACCq
-        ACCn = kfield.fe_mul(F, self.limbs(ACCq), dx2, out=self.limbs(ACCq), tag="p6")  # in place (write-after-read ordered)
+        ACCn = kfield.fe_mul(F, self.limbs(ACCq), dx2, out=self.limbs(ACCq), tag=T("p6"))  # in place (write-after-read ordered)
         # distinguished point?  (x.limb3 & dpMask) == 0, GPUCompute.h:96
-        t1, t2 = A.v("dpt1"), A.v("dpt2")
+        t1, t2 = A.v(T("dpt1")), A.v(T("dpt2"))
         A.v_and_b32(t1, self.dp_mask_lo, RX[6])
         A.v_and_b32(t2, self.dp_mask_hi, RX[7])
         A.v_or_b32(t1, t1, t2)
-        DPM = A.st("dpm", 2)
+        DPM = A.st(T("dpm"), 2)
         A.v_cmp_eq_u32(DPM, 0, t1)
         # everything the stores and the commit need must be complete here
         A.keep(*INVn, *RX, *RY, *ACCn, *DN.regs[:2 if self.dsplit else 4], DPM)
@@ -225,26 +258,26 @@ class Loop:
         A.s_cbranch_scc1(L_rare)
         # ---------------- block B: stores, DP records, commit
         A.cur.name = "B"
-        voff8 = A.v("voff8")
-        A.v_lshrrev_b32(voff8, 1, self.voff)
-        A.global_store(4, self.voff, RXq[0], self.P["x01"], nt=True)
-        A.global_store(4, self.voff, RXq[1], self.P["x23"], nt=True)
-        A.global_store(4, self.voff, RYq[0], self.P["y01"], nt=True)
-        A.global_store(4, self.voff, RYq[1], self.P["y23"], nt=True)
+        voff8 = A.v(T("voff8"))
+        A.v_lshrrev_b32(voff8, 1, voff)
+        A.global_store(4, voff, RXq[0], self.P["x01"], nt=True)
+        A.global_store(4, voff, RXq[1], self.P["x23"], nt=True)
+        A.global_store(4, voff, RYq[0], self.P["y01"], nt=True)
+        A.global_store(4, voff, RYq[1], self.P["y23"], nt=True)
         A.global_store(2, voff8, DN.sub(0, 2), self.P["dlo"])
         if not self.dsplit:
             A.global_store(2, voff8, DN.sub(2, 2), self.P["dhi"])
-        A.global_store(4, self.voff, ACCq[0], self.P["s01"])
-        A.global_store(4, self.voff, ACCq[1], self.P["s23"])
+        A.global_store(4, voff, ACCq[0], self.P["s01"])
+        A.global_store(4, voff, ACCq[1], self.P["s23"])
         A.s_cmp("lg_u64", DPM, 0)
         A.s_cbranch_scc0(L_nodp)
         # ---- cold: wave-compacted DP records (emit_dp of kng_engine.hip; GPUCompute.h:96-105)
         A.cur.schedule = False
         A.raw("; cold path")
-        SAVE, ONE, KEEP = A.st("save", 2), A.st("one", 2), A.st("keep", 2)
-        scnt, slead, sbase = A.s("scnt"), A.s("slead"), A.s("sbase")
-        vpos, vcnt, vzero, vbase, vrec = A.v("vpos"), A.v("vcnt"), A.v("vzero"), A.v("vbase"), A.v("vrec")
-        KQ = A.vt("kq", 4)
+        SAVE, ONE, KEEP = A.st(T("save"), 2), A.st(T("one"), 2), A.st(T("keep"), 2)
+        scnt, slead, sbase = A.s(T("scnt")), A.s(T("slead")), A.s(T("sbase"))
+        vpos, vcnt, vzero, vbase, vrec = A.v(T("vpos")), A.v(T("vcnt")), A.v(T("vzero")), A.v(T("vbase")), A.v(T("vrec"))
+        KQ = A.vt(T("kq"), 4)
         A.s_mov_b64(SAVE, EXEC)
         if self.dsplit:
             A.s_mov_exec(DPM)
@@ -265,7 +298,7 @@ class Loop:
         A.v_add_u32(vpos, sbase, vpos)
         A.v_cmp_lt_u32(KEEP, vpos, self.max_found)
         A.v_lshlrev_b32(vrec, 6, vpos)
-        A.v_lshrrev_b32(KQ[0], 4, self.voff)
+        A.v_lshrrev_b32(KQ[0], 4, voff)
         A.v_mov_b32(KQ[1], 0)
         A.v_mov_b32(KQ[2], 0)
         A.v_mov_b32(KQ[3], 0)
@@ -276,22 +309,23 @@ class Loop:
         A.global_store(4, vrec, DN, self.dp_items, offset=32)
         A.global_store(4, vrec, KQ, self.dp_items, offset=48)
         A.s_mov_exec(SAVE)
-        # ---- commit (the prefetch must have landed: everything issued behind it may still be in flight)
+        # ---- the prefetch must have landed: everything issued behind it may still be in flight
         A.label(L_nodp)
         A.cur.schedule = False
         n_after = 7 if self.dsplit else 8  # stores of this iteration issued behind the prefetch loads (x, y: 4; d: 1 or 2; products: 2)
-        A.s_waitcnt(vmcnt=n_after, regs=self.NX + self.NY + [self.ND.sub(0, 2)] + ([] if self.dsplit else [self.ND.sub(2, 2)]) + self.NB)
-        A.block("commit")
-        for d, s_ in zip(self.INV, INVn):
-            A.v_mov_b32(d, s_)
-        for dq, sq in ((self.CX, self.NX), (self.CY, self.NY)):
-            for d, s_ in zip(self.limbs(dq), self.limbs(sq)):
+        A.s_waitcnt(vmcnt=n_after, regs=NX + NY + [ND.sub(0, 2)] + ([] if self.dsplit else [ND.sub(2, 2)]) + self.NB)
+        if copy_back:
+            A.block("commit")
+            for d, s_ in zip(INV, INVn):
                 A.v_mov_b32(d, s_)
-        for i in range(2 if self.dsplit else 4):
-            A.v_mov_b32(self.CD[i], self.ND[i])
-        A.v_mov_b32(self.voff, voffn)
+            for dq, sq in ((CX, NX), (CY, NY)):
+                for d, s_ in zip(self.limbs(dq), self.limbs(sq)):
+                    A.v_mov_b32(d, s_)
+            for i in range(2 if self.dsplit else 4):
+                A.v_mov_b32(CD[i], ND[i])
+            A.v_mov_b32(voff, voffn)
         A.block("next", schedule=False)
-        k1b = A.s("k1b")
+        k1b = A.s(T("k1b"))
         A.s_add_u32(self.k, self.k, 1)
         A.s_add_u32(k1b, self.k, 1)
         A.s_cmp("lt_u32", k1b, self.G)
@@ -301,18 +335,17 @@ class Loop:
         A.label(L_fix)
         A.cur.schedule = False
         A.s_cmp("lt_u32", self.k, self.G)
-        A.s_cbranch_scc1(L_loop)
-        # ================= exits =================
+        A.s_cbranch_scc1(L_next)
+        A.cur.schedule = False
+        A.s_branch(L_exit)
+        # ---- exact-path exit of this copy: the caller gets the running inverse as it was BEFORE this kangaroo
         A.label(L_rare)
         A.cur.schedule = False
         A.raw("; cold path")
-        A.label(L_exit)
-        A.cur.schedule = False
-        for d, s_ in zip(self.ACCop, self.limbs(self.ACCq)):
-            A.v_mov_b32(d, s_)  # (undefined after an exact-path exit: P6 may have started to overwrite it)
-        A.s_waitcnt(vmcnt=0, lgkmcnt=0)
-        A.s_nop(1)
-        return self
+        if INV is not self.INV:
+            for d, s_ in zip(self.INV, INV):
+                A.v_mov_b32(d, s_)
+        A.s_branch(L_exit)
 
 
 VPOOL = list(range(64, 256))
