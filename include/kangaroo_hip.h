@@ -144,8 +144,8 @@ int kng_last_kernel_ms(const kng_engine *h, float *ms);
  *   "lanes"  alternatively the lane count itself (multiple of 64, need not divide the herd: waves then
  *            walk ceil or floor of herd/lanes kangaroos)
  *   "block"  threads per workgroup (multiple of 64)
- *   "share"  waves of one SIMD that share one modular inversion per jump: 1 = none (256-thread blocks),
- *            2 (default) = waves w, w+4 of a 512-thread block ("block" is then ignored)
+ *   "share"  waves that share one modular inversion per jump: 1 = none (256-thread blocks), 8 (default) = the eight
+ *            waves of a 512-thread block, i.e. one inversion per CU ("block" is then ignored)
  *   "dsplit" -1 (default): stream only the low word of the 128-bit distances through HBM when every jump
  *            distance given to kng_set_params is below 2^50 (the high word is then updated on the rare carry);
  *            0 = never, 1 = whenever the table allows it (all high words zero).  Reads back 0/1 = in effect.

@@ -245,12 +245,11 @@ KNG_DEV void walk_core(const WalkArgs &a, const uint64_t *tab, uint64_t *dlo, ui
 
 // The hot kernel.  Replaces comp_kangaroos/ComputeKangaroos (GPUEngine.cu:35-40, GPUCompute.h:22-117).
 //
-// SHARE = 2 (512-thread blocks, option "share"): the two waves that occupy one SIMD (waves w, w+4
-// of the block) share ONE inversion per jump.  Waves w+4.. park their lane products in LDS and wait at
-// the barrier; wave w inverts the product of all chains and hands the individual inverses back, e.g.
-//     i = 1/(acc*pb) ;  1/acc = i*pb ;  1/pb = i*acc          (3 extra multiplications per lane pair)
-// Two co-resident waves inverting side by side need ~2 x 55K SIMD cycles per jump of the pair; one wave
-// alone on the SIMD needs ~61K.  Results are unchanged (the canonical residue is the same).
+// SHARE = 8 (512-thread blocks, option "share", the default): the eight waves of a CU share ONE inversion per jump
+// through a two-level product tree (see the step loop).  Round 1-2's SHARE = 2 (one inversion per SIMD: waves w and
+// w+4) is its first level; sharing the whole CU is +2.5 % on top (profiles/r03_ab_share8.txt) and replaced it.
+//     i = 1/(a*b) ;  1/a = i*b ;  1/b = i*a          (3 multiplications per pair and level)
+// Results are unchanged (the canonical residue is the same).
 //
 // DSPLIT = true: the 128-bit distance only streams its LOW word through HBM.  d += jD[j] carries out of bit 64
 // with probability jD/2^64 (2^-23 per jump at an 80-bit range); the high word is read-modified-written on
@@ -285,38 +284,52 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
     for (uint32_t step = 0; step < a.nsteps; step++) {
         // one inversion per lane per jump of the whole group (GPUMath.h:1179-1180)
         fe inv;
-        if (SHARE > 1) {
-            // chains 0..SHARE-1 of this lane pair-up: chain c is thread pair + 256*c
-            const uint32_t pair = threadIdx.x & 255, chain = threadIdx.x >> 8;
-            if (chain) {
-                xch[(2 * chain - 2) * 256 + pair] = make_ulonglong2(acc.v[0], acc.v[1]);
-                xch[(2 * chain - 1) * 256 + pair] = make_ulonglong2(acc.v[2], acc.v[3]);
+        if (SHARE == 8) {
+            // ONE inversion per CU and jump: the eight waves of the 512-thread block (two per SIMD) form a two-level
+            // product tree.  Level 1 as for SHARE = 2 (waves w and w+4, four SIMDs side by side: 1 multiplication up,
+            // 2 down); level 2: wave 0 multiplies the four pair products (3), inverts ONCE, and walks back (6).
+            // 3 of the 4 inversions of a CU-step (17 K instructions each) are traded for 9 serial multiplications
+            // and two more barriers.  xch: slot s = two 64-lane rows of 16-byte halves.
+            const uint32_t col = threadIdx.x & 63, w = threadIdx.x >> 6;
+            auto put = [&](uint32_t slot, const fe &v) {
+                xch[(2 * slot) * 64 + col] = make_ulonglong2(v.v[0], v.v[1]);
+                xch[(2 * slot + 1) * 64 + col] = make_ulonglong2(v.v[2], v.v[3]);
+            };
+            auto get = [&](uint32_t slot) -> fe {
+                const v16 b0 = xch[(2 * slot) * 64 + col], b1 = xch[(2 * slot + 1) * 64 + col];
+                return fe{{b0.x, b0.y, b1.x, b1.y}};
+            };
+            if (w >= 4) put(w, acc);
+            __syncthreads();
+            fe pb = fe_one(), pre = fe_one(), i = fe_one();
+            if (w < 4) {
+                pb = get(w + 4);
+                pre = fe_mul(acc, pb);
+                if (w) put(w, pre);
             }
             __syncthreads();
-            if (!chain) {
-                fe pb[SHARE], pre[SHARE]; // partner products, prefix products acc*pb[1]*..*pb[c]
-                pre[0] = acc;
-#pragma unroll
-                for (int c = 1; c < SHARE; c++) {
-                    const v16 b0 = xch[(2 * c - 2) * 256 + pair], b1 = xch[(2 * c - 1) * 256 + pair];
-                    pb[c] = fe{{b0.x, b0.y, b1.x, b1.y}};
-                    pre[c] = fe_mul(pre[c - 1], pb[c]);
-                }
-                fe i = fe_inv(pre[SHARE - 1]);
-#pragma unroll
-                for (int c = SHARE - 1; c >= 1; c--) {
-                    const fe ib = fe_mul(i, pre[c - 1]); // 1/pb[c]
-                    i = fe_mul(i, pb[c]);                // 1/pre[c-1]
-                    xch[(2 * c - 2) * 256 + pair] = make_ulonglong2(ib.v[0], ib.v[1]);
-                    xch[(2 * c - 1) * 256 + pair] = make_ulonglong2(ib.v[2], ib.v[3]);
-                }
-                inv = i;
+            if (w == 0) {
+                const fe q1 = get(1), q2 = get(2), q3 = get(3);
+                const fe m1 = fe_mul(pre, q1), m2 = fe_mul(m1, q2), m3 = fe_mul(m2, q3);
+                fe t = fe_inv(m3);
+                const fe i3 = fe_mul(t, m2); // 1/q3
+                t = fe_mul(t, q3);           // 1/m2
+                const fe i2 = fe_mul(t, m1); // 1/q2
+                t = fe_mul(t, q2);           // 1/m1
+                const fe i1 = fe_mul(t, pre); // 1/q1
+                i = fe_mul(t, q1);            // 1/pre of wave 0
+                put(1, i1);
+                put(2, i2);
+                put(3, i3);
             }
             __syncthreads();
-            if (chain) {
-                const v16 b0 = xch[(2 * chain - 2) * 256 + pair], b1 = xch[(2 * chain - 1) * 256 + pair];
-                inv = fe{{b0.x, b0.y, b1.x, b1.y}};
+            if (w > 0 && w < 4) i = get(w);
+            if (w < 4) {
+                put(w + 4, fe_mul(i, acc)); // 1/pb
+                inv = fe_mul(i, pb);        // 1/acc
             }
+            __syncthreads();
+            if (w >= 4) inv = get(w);
             if (G == 0) continue;
         } else {
             inv = fe_inv(acc);
@@ -391,13 +404,13 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
     }
 }
 
-// SHARE = 1: 256-thread blocks, every wave inverts for itself (small herds, option "share").  SHARE = 2: 512-thread
-// blocks, waves w and w+4 share one inversion.  (Round 2 also carried SHARE = 3 and two non-template twins of <1,.>;
-// share 3 lost at every herd size, profiles/r02_group_share_sweep.txt, and was dropped in round 3.)
+// SHARE = 1: 256-thread blocks, every wave inverts for itself (option "share": a reference point and the form that needs
+// no barrier).  SHARE = 8: 512-thread blocks, one inversion per CU.  (Round 2 also carried SHARE = 2, SHARE = 3 and two
+// non-template twins of <1,.>: share 3 lost at every herd size, profiles/r02_group_share_sweep.txt; share 2 loses to 8.)
 template <int SHARE, bool DSPLIT, bool ASM>
-__global__ void __launch_bounds__(256 * SHARE) kng_walk_share_kernel(const WalkArgs a) {
+__global__ void __launch_bounds__(SHARE == 1 ? 256 : 512) kng_walk_share_kernel(const WalkArgs a) {
     __shared__ uint64_t tab[JT_WORDS];
-    __shared__ v16 xch[SHARE > 1 ? 512 * (SHARE - 1) : 1];
+    __shared__ v16 xch[SHARE == 8 ? 1024 : 1];
     for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
     __syncthreads();
     walk_body<SHARE, DSPLIT, ASM>(a, tab, xch);
@@ -591,7 +604,7 @@ struct kng_engine {
     int dsplit = -1;       // distance plane: -1 = low-word streaming when every jump distance < 2^50, 0 = never, 1 = whenever the table allows (high words all zero)
     bool dsplit_on = false; // decided by kng_set_params / the option
     uint64_t jd_max = 0;    // largest low word of the jump distances, UINT64_MAX when a high word is set
-    int share = 2;         // waves per SIMD (w, w+4) of one 256*share-thread block that share one inversion per jump
+    int share = 8;         // waves of a 512-thread block (= of a CU at the bench geometry) that share one inversion per jump
     int use_asm = 1;       // the scheduled asm loop (kng_walk_asm.h) instead of the compiler-scheduled one; herds beyond 2^28 cannot
     WalkAsmArgs *asm_args = nullptr; // device: one block per DP buffer
     v16 *planes = nullptr; // 7 planes of n v16
@@ -819,7 +832,7 @@ int kng_set_option(kng_engine *h, const char *key, int64_t value) {
         h->dsplit = (int)value;
         decide_dsplit(h);
     } else if (k == "share") {
-        if (value < 1 || value > 2) return fail(KNG_E_ARG, "share must be 1 or 2");
+        if (value != 1 && value != 8) return fail(KNG_E_ARG, "share must be 1 (every wave inverts) or 8 (one inversion per CU)");
         h->share = (int)value;
     } else if (k == "dp_ring") {
         if (value < 0 || value > 1) return fail(KNG_E_ARG, "dp_ring must be 0 or 1");
@@ -1039,9 +1052,9 @@ int kng_launch(kng_engine *h) {
     const bool ds = h->dsplit_on;
     const dim3 grid2((h->lanes + 511) / 512), grid1(blocks);
 #define KNG_LAUNCH(SH, DS, AS, GRID, BLOCK) hipLaunchKernelGGL((kng_walk_share_kernel<SH, DS, AS>), GRID, dim3(BLOCK), 0, h->walk, a)
-    if (h->share == 2) {
-        if (h->use_asm) { if (ds) KNG_LAUNCH(2, true, true, grid2, 512); else KNG_LAUNCH(2, false, true, grid2, 512); }
-        else { if (ds) KNG_LAUNCH(2, true, false, grid2, 512); else KNG_LAUNCH(2, false, false, grid2, 512); }
+    if (h->share == 8) { // one inversion per CU
+        if (h->use_asm) { if (ds) KNG_LAUNCH(8, true, true, grid2, 512); else KNG_LAUNCH(8, false, true, grid2, 512); }
+        else { if (ds) KNG_LAUNCH(8, true, false, grid2, 512); else KNG_LAUNCH(8, false, false, grid2, 512); }
     } else {
         if (h->use_asm) { if (ds) KNG_LAUNCH(1, true, true, grid1, h->block); else KNG_LAUNCH(1, false, true, grid1, h->block); }
         else { if (ds) KNG_LAUNCH(1, true, false, grid1, h->block); else KNG_LAUNCH(1, false, false, grid1, h->block); }

@@ -144,6 +144,9 @@ KNG_DEV fe fe_fold32_full(const uint32_t w[16]) {
 // d = a*b + c (32x32+64 -> 64), carry-out of the 64-bit sum in `co` (an SGPR lane mask on the device: the
 // conditions below are therefore wave-uniform "some lane overflowed" tests that cost no VALU instruction)
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+#if !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "KNG_MAD64: the carry-out is a 64-bit SGPR lane mask and vdst carries no early-clobber -- valid for wave64 gfx9 only"
+#endif
 #define KNG_MAD64(d, co, a, b, c) asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(co) : "v"(a), "s"(b), "v"(c))
 #else
 #define KNG_MAD64(d, co, a, b, c)                                                                          \

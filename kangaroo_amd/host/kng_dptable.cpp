@@ -38,7 +38,10 @@ struct Fine {
 };
 
 // ---- arena allocator: size classes 64, 96, 128, 192, 256, 384, ... bytes (class c: 64 << c/2, times 1.5 when c is odd) ----
-constexpr int MIN_CLASS = 0, MAX_CLASS = 32;          // 64 B .. 4 MiB
+// 64 B .. 1 GiB.  Blocks above REGION get a mapping of their own (arena_alloc: want = sz): a skewed bucket -- one run with
+// more than 131 072 entries, or the 2^k run headers of a bucket split 2^20 ways and beyond -- must not end as "out of memory"
+// while memory is there.
+constexpr int MIN_CLASS = 0, MAX_CLASS = 48;
 constexpr size_t REGION_MIN = (size_t)64 << 10;       // an arena's first region; each further one doubles ...
 constexpr size_t REGION = (size_t)2 << 20;            // ... up to this (a small table must not cost N_ARENAS x 2 MiB)
 constexpr unsigned ARENA_BITS = 6, N_ARENAS = 1u << ARENA_BITS;
@@ -118,6 +121,7 @@ struct Bucket {
     Fine *fine = nullptr; // 1 << k arrays, ordered by the top k bits of x[1]
     uint32_t n = 0;       // entries in the whole bucket (nbItem)
     uint32_t ref_max = 0; // the reference's maxItem bookkeeping (file compatibility only)
+    uint32_t split_retry = 0; // a re-split that failed (no memory for the finer layout) is tried again once n reaches this
     uint8_t k = 0;
 };
 
@@ -202,6 +206,7 @@ bool resplit(Arena &a, Bucket &b, uint8_t k, std::vector<kngt_entry> &scratch) {
     if (!build(a, nb, k, scratch.data(), b.n)) return false; // keep the old layout: still correct, only slower
     nb.n = b.n;
     nb.ref_max = b.ref_max;
+    nb.split_retry = 0;
     free_bucket(a, b);
     b = nb;
     return true;
@@ -338,9 +343,12 @@ int kngt_add_entry(kngt_table *t, uint32_t h, const kngt_entry *e, kngt_entry *o
     f.e[lo] = *e;
     f.n++;
     b.n++;
-    if (b.k < K_MAX && b.n > (SPLIT_AVG << b.k)) {
+    if (b.k < K_MAX && b.n > (SPLIT_AVG << b.k) && b.n >= b.split_retry) {
         thread_local std::vector<kngt_entry> scratch;
-        (void)resplit(ar, b, (uint8_t)(b.k + 2), scratch);
+        // a failed re-split keeps the old (correct, slower) layout; gathering the whole bucket again on every insert
+        // would make each one cost O(n): try again when the bucket has doubled
+        if (resplit(ar, b, (uint8_t)(b.k + 2), scratch)) b.split_retry = 0;
+        else b.split_retry = b.n > 0x7FFFFFFFu ? 0xFFFFFFFFu : 2 * b.n;
     }
     return KNGT_ADD_OK;
 }

@@ -132,7 +132,8 @@ struct kngs_solver {
 
     // restored herds
     kngw_file *herd_file = nullptr;
-    uint64_t herd_left = 0;
+    uint64_t herd_left = 0, herd_total = 0;
+    bool herd_spent = false; // a failed kngs_prepare had already taken kangaroos from the work file
     uint64_t herd_loaded = 0, herd_created = 0;
     uint64_t seed_used = 0;
     bool prepared = false;    // engines created, herds in place (kngs_prepare)
@@ -489,7 +490,8 @@ int kngs_load(kngs_solver *s, const char *path) {
     s->offset_seconds = h.total_seconds;
     if (s->herd_file) kngw_close(s->herd_file);
     s->herd_file = f;
-    s->herd_left = n;
+    s->herd_left = s->herd_total = n;
+    s->herd_spent = false;
     return 0;
 }
 
@@ -529,8 +531,12 @@ int kngs_prepare(kngs_solver *s) {
     if (!s) return fail("null argument");
     if (s->started) return fail("already started");
     if (s->prepared) return 0;
+    if (s->herd_spent)
+        return fail("an earlier kngs_prepare failed after kangaroos had been read from the work file: load the file again (kngs_load) before retrying");
     const kngs_config &cfg = s->cfg;
-    // a failed start leaves the solver as it was before the call: no half-built workers to trip a second attempt
+    // a failed start leaves the solver as it was before the call: no half-built workers to trip a second attempt.  The one
+    // thing that cannot be put back is the read position of the work file: a retry would silently create fresh kangaroos in
+    // place of the ones already taken, so it is refused until the file has been loaded again.
     auto undo = [&](int rc) {
         for (Worker *w : s->workers) {
             if (w->eng) kng_destroy(w->eng);
@@ -538,9 +544,14 @@ int kngs_prepare(kngs_solver *s) {
         }
         s->workers.clear();
         s->herd_loaded = s->herd_created = 0;
+        if (s->herd_file && s->herd_left != s->herd_total) s->herd_spent = true;
         s->prepared = false;
         return rc;
     };
+    // warm-up launches are a benchmarking aid: they walk the herd and throw the distinguished points away.  On a herd
+    // restored from a work file that would drop trails the table never sees and under-count the work done.
+    if (cfg.warmup_launches && s->herd_file && s->herd_left)
+        return fail("warmup_launches with a loaded work file would discard distinguished points of the restored herd");
     // seed 0 = draw one: two runs (or a resumed run) must not rebuild the same herds -- their walks would retrace
     // trails already in the table and every point would come back as a duplicate
     s->seed_used = cfg.seed ? cfg.seed : draw_seed();
@@ -606,6 +617,7 @@ int kngs_prepare(kngs_solver *s) {
             uint32_t n_items, n_lost;
             if (kng_wait(w->eng, 0) != KNG_OK || kng_drain_view(w->eng, &rec, &n_items, &n_lost) != KNG_OK)
                 return undo(fail("warm-up launch: %s", kng_last_error()));
+            s->offset_count += w->n * KNG_NB_RUN; // the herd did advance: the saved total must say so
         }
     }
     s->prepared = true;

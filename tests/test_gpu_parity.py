@@ -331,10 +331,10 @@ def test_full_size_herd_properties(kng, orc):
 
 
 @pytest.mark.parametrize("use_asm", [1, 0])
-@pytest.mark.parametrize("share", [1, 2])
+@pytest.mark.parametrize("share", [1, 8])
 @pytest.mark.parametrize("rp,dsplit", [(72, 1), (109, 0)])
 def test_every_walk_kernel_vs_oracle(kng, orc, share, rp, dsplit, use_asm):
-    """All eight instantiations of the walk kernel -- share 1/2 x {low-word distance streaming, both words} x {scheduled
+    """All eight instantiations of the walk kernel -- share 1/8 x {low-word distance streaming, both words} x {scheduled
     asm loop, compiler-scheduled loop} -- as the engine itself selects them: a 72-bit range streams only the low word,
     BASELINE configs[3]'s 109-bit range (jump distances around 2^54) streams both.  States and the exact DP multiset
     over two launches."""
@@ -422,7 +422,7 @@ def test_bench_config_total_parity(kng, orc, dsplit):
     mask = hl.dp_mask(dp)
     with kng.GPUEngine(gx, gy, 0, 1 << 17, dsplit=dsplit) as eng:
         eng.SetParams(mask, jd, jx, jy)
-        assert eng.get_option("dsplit") == dsplit and eng.get_option("share") == 2 and eng.get_option("group") == 64
+        assert eng.get_option("dsplit") == dsplit and eng.get_option("share") == 8 and eng.get_option("group") == 64
         eng.CreateHerdOnDevice(rp, (kx, ky), seed=0xBEEF + dsplit)
         x0, y0, d0 = eng.GetKangaroos(raw=True)
         eng.callKernel()
@@ -712,7 +712,7 @@ def test_ragged_groups_vs_oracle(kng, orc, grid, lanes):
     eng.close()
 
 
-@pytest.mark.parametrize("share", [1, 2])
+@pytest.mark.parametrize("share", [1, 8])
 def test_distance_low_word_streaming_vs_oracle(kng, orc, share):
     """Option "dsplit": only the low word of the 128-bit distance streams through HBM; the high word is
     read-modified-written when the add carries and fetched when a DP is emitted.  Forced on with jump distances
@@ -796,11 +796,11 @@ def test_ranged_set_get_of_the_herd(kng):
     eng.close()
 
 
-@pytest.mark.parametrize("share", [2])
+@pytest.mark.parametrize("share", [8])
 @pytest.mark.parametrize("grid,opt", [((4, 4), dict(group=4)), ((4, 4), dict(group=128)), ((3, 5), dict(lanes=448)),
                                       ((2, 3), dict(lanes=320)), ((8, 4), dict(group=2))])
 def test_shared_inversion_vs_oracle(kng, orc, grid, opt, share):
-    """Option "share": waves w, w+4 of a 512-thread block invert the product of their lane chains once.
+    """Option "share": the eight waves of a 512-thread block invert the product of their lane chains once (two-level tree).
     Covers full blocks, a partner wave without work (lanes % 512 != 0) and ragged groups; three launches."""
     n = grid[0] * grid[1] * 128
     rp = 72
