@@ -344,18 +344,45 @@ def main():
     if world != args.gpus and world > 1:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}")
     n_gpus = world if world > 1 else max(1, args.gpus)
+    per_rank_note = None
     if n_gpus > 1:
-        return bench_multi(args, ranks, n_gpus)
+        # The N-GPU job is ONE process over all devices (one shared DP table).  That needs rank 0 to see them all; a launcher
+        # that pins each rank to its own device (ROCR_/HIP_VISIBLE_DEVICES per rank) leaves it one.  Decided collectively, so
+        # that nobody waits in a barrier for a rank that has left: then every rank walks its own herd on the device it can see
+        # and drains its own distinguished points (kernel path identical; the shared table is what that form cannot show).
+        seen = -1
+        if rank == 0:
+            try:
+                import kangaroo_amd as k0
+
+                k0.load_library()
+                seen = k0.device_count()
+            except Exception as e:  # noqa: BLE001 -- reported below, on every rank
+                log(f"bench --gpus {n_gpus}: rank 0 cannot load the engine: {e!r}")
+        one_process = ranks.all_ok(rank != 0 or bool(args.devices) or seen >= n_gpus)
+        if one_process or world == 1:
+            return bench_multi(args, ranks, n_gpus)
+        per_rank_note = (f"rank 0 sees {seen} of {n_gpus} devices: one process per GPU, every rank drains its own distinguished points "
+                         f"(no shared host table in this form)")
+        if rank == 0:
+            log(f"bench --gpus {n_gpus}: {per_rank_note}")
 
     import numpy as np
 
     import kangaroo_amd as k
     import kangaroo_amd.hostlib as hl
 
-    k.load_library()  # raises when the HIP engine is missing: no fallback
-    if k.device_count() <= local_rank:
-        raise SystemExit(f"rank {rank}: no HIP device {local_rank}")
-    dev = local_rank
+    have = 0
+    try:
+        k.load_library()  # raises when the HIP engine is missing: no fallback
+        have = k.device_count()
+    except Exception as e:  # noqa: BLE001
+        log(f"rank {rank}: {e!r}")
+    if not ranks.all_ok(have > 0 and (world == 1 or per_rank_note is not None or have > local_rank)):
+        log(f"rank {rank}: sees {have} HIP device(s), needs device {local_rank}")
+        ranks.abort()
+        raise SystemExit(1)  # every rank leaves, promptly
+    dev = local_rank if local_rank < have else local_rank % have  # pinned launchers expose each rank's device as device 0
     info = k.device_info(dev)
 
     if args.grid:
@@ -451,7 +478,7 @@ def main():
             "range_power": RANGE_POWER, "dp": dp, "grid": [gx, gy], "kangaroos_per_gpu": n,
             "group": eng.get_option("group"), "lanes": eng.get_option("lanes"), "share": eng.get_option("share"), "asm_loop": eng.get_option("asm"),
             "device": info["name"], "arch": info["arch"],
-            "parallelism": f"independent herds x{n_gpus}, no collective",
+            "parallelism": f"independent herds x{n_gpus}, no collective" + (f"; {per_rank_note}" if per_rank_note else ""),
             "dps_per_step": round(dps / args.steps, 1), "dps_lost": lost,
         },
         "roofline": roof,

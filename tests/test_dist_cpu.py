@@ -88,3 +88,85 @@ def test_single_rank_needs_no_torch_distributed():
         for k, v in env_backup.items():
             if v is not None:
                 os.environ[k] = v
+
+
+FAIL_WORKER = textwrap.dedent("""
+    import os, sys, time
+    sys.path.insert(0, %r)
+    from kangaroo_amd.dist import Ranks, RankFailure, timed_on_rank0
+    r = Ranks(backend="gloo")
+    mode = os.environ["KNG_FAIL_MODE"]
+    if mode == "prepare":
+        # bench_multi's preparation protocol: rank 0 fails BEFORE the timed region, says so through all_ok(), everyone leaves
+        err = RuntimeError("rank 0 sees 1 HIP device, needs 2") if r.rank == 0 else None
+        if not r.all_ok(err is None):
+            r.abort()
+            sys.exit(3)
+        sys.exit(0)
+    def job():
+        time.sleep(0.05)
+        raise RuntimeError("engine failed in launch 3")
+    try:
+        timed_on_rank0(r, job if r.rank == 0 else None)
+    except RankFailure as e:
+        print("RANKFAILURE", r.rank, e, flush=True)
+        r.abort()
+        sys.exit(3)
+    sys.exit(0)
+""") % ROOT
+
+
+def _run_two_ranks(script, extra_env, timeout, args=()):
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), **extra_env)
+        procs.append(subprocess.Popen([sys.executable, str(script), *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=timeout)
+            outs.append((p.returncode, out, err))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return outs
+
+
+def test_rank0_failure_ends_every_rank(tmp_path):
+    """when rank 0's job (the only rank that works) fails, BOTH ranks must leave non-zero promptly --
+    nobody may sit in a barrier until the launcher's timeout.  Covers the timed region and the preparation before it."""
+    import time
+
+    script = tmp_path / "fail_worker.py"
+    script.write_text(FAIL_WORKER)
+    for mode in ("job", "prepare"):
+        t0 = time.time()
+        outs = _run_two_ranks(script, {"KNG_FAIL_MODE": mode}, timeout=120)
+        took = time.time() - t0
+        assert [rc for rc, _, _ in outs] == [3, 3], (mode, outs)
+        assert took < 90, f"{mode}: {took:.0f} s"
+        if mode == "job":
+            assert all("RANKFAILURE" in out for _, out, _ in outs), outs
+            assert "engine failed in launch 3" in outs[0][1]  # rank 0 knows why; rank 1 knows that
+
+
+def test_bench_two_ranks_without_devices_ends_promptly():
+    """`bench.py --gpus 2` as the driver launches it (one rank per GPU, gloo control plane) on a box where NO rank has a
+    device: the visibility vote sends both ranks to the per-rank form, the device check fails collectively, and both leave
+    with status 1 -- no rank is left in a barrier."""
+    import time
+
+    import torch
+
+    if torch.cuda.is_available():
+        import pytest
+
+        pytest.skip("needs a box without GPUs")
+    t0 = time.time()
+    outs = _run_two_ranks(os.path.join(ROOT, "bench.py"), {}, timeout=240, args=("--gpus", "2", "--steps", "2", "--warmup", "1"))
+    assert [rc for rc, _, _ in outs] == [1, 1], outs
+    assert time.time() - t0 < 200
+    assert "sees 0 of 2 devices" in outs[0][2] or "sees 0 HIP device" in outs[0][2], outs[0][2][-600:]

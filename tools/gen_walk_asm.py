@@ -78,6 +78,12 @@ class Loop:
         self.F = kfield.Field(A, self.k977, self.rare)
         self.F.elide_first_carry = os.environ.get("KASM_ELIDE", "0") == "1"
         self.unroll = int(os.environ.get("KASM_UNROLL", "2"))
+        # measurement builds only (WRONG results on purpose, see tools/r3_sensitivity.sh): comma list of
+        #   nos      no traffic of the product planes S (the neighbour product is whatever the registers hold)
+        #   nosA     ... in iteration A only           } together: the cost/benefit proxy of storing every OTHER
+        #   plusmulA one extra product in iteration A  } prefix product (-32 B/jump, +1/2 multiplication per jump)
+        #   nostore  x, y, d not written back
+        self.abl = set(filter(None, os.environ.get("KASM_ABL", "").split(",")))
 
     @staticmethod
     def limbs(quads):
@@ -208,10 +214,15 @@ class Loop:
         IK = kfield.fe_mul(F, INV, nb, tag=T("p1"))
         # the product behind the next kangaroo, straight into the registers P1 has just read (write-after-read
         # dependencies place the loads behind P1's last multiply): no second register set, no moves
-        self.load_fe(self.NB, voffnn, "s01", "s23", False)
+        no_s = "nos" in self.abl or ("nosA" in self.abl and tag == "a")
+        if not no_s:
+            self.load_fe(self.NB, voffnn, "s01", "s23", False)
         dx = kfield.fe_sub(F, cx, jx, tag=T("dx"), k977_v=self.v977)
         dy = kfield.fe_sub(F, cy, jy, tag=T("dy"), k977_v=self.v977)
         INVn = kfield.fe_mul(F, INV, dx, out=nxt["INV"], tag=T("p2"))
+        if "plusmulA" in self.abl and tag == "a":
+            XM = kfield.fe_mul(F, dx, dy, tag=T("px"))  # measurement only: the extra product of the every-other-product form
+            dy = kfield.fe_sub(F, XM, jy, tag=T("dyx"), k977_v=self.v977)  # (kept alive by feeding P3)
         # P3: s = dy * invk ; P4: s^2
         S = kfield.fe_mul(F, dy, IK, tag=T("p3"))
         SQ = kfield.fe_sqr(F, S, tag=T("p4"))
@@ -260,15 +271,21 @@ class Loop:
         A.cur.name = "B"
         voff8 = A.v(T("voff8"))
         A.v_lshrrev_b32(voff8, 1, voff)
-        A.global_store(4, voff, RXq[0], self.P["x01"], nt=True)
-        A.global_store(4, voff, RXq[1], self.P["x23"], nt=True)
-        A.global_store(4, voff, RYq[0], self.P["y01"], nt=True)
-        A.global_store(4, voff, RYq[1], self.P["y23"], nt=True)
-        A.global_store(2, voff8, DN.sub(0, 2), self.P["dlo"])
-        if not self.dsplit:
-            A.global_store(2, voff8, DN.sub(2, 2), self.P["dhi"])
-        A.global_store(4, voff, ACCq[0], self.P["s01"])
-        A.global_store(4, voff, ACCq[1], self.P["s23"])
+        n_after = 0  # stores of this iteration issued behind the prefetch loads
+        if "nostore" not in self.abl:
+            A.global_store(4, voff, RXq[0], self.P["x01"], nt=True)
+            A.global_store(4, voff, RXq[1], self.P["x23"], nt=True)
+            A.global_store(4, voff, RYq[0], self.P["y01"], nt=True)
+            A.global_store(4, voff, RYq[1], self.P["y23"], nt=True)
+            A.global_store(2, voff8, DN.sub(0, 2), self.P["dlo"])
+            n_after += 5
+            if not self.dsplit:
+                A.global_store(2, voff8, DN.sub(2, 2), self.P["dhi"])
+                n_after += 1
+        if not no_s:
+            A.global_store(4, voff, ACCq[0], self.P["s01"])
+            A.global_store(4, voff, ACCq[1], self.P["s23"])
+            n_after += 2
         A.s_cmp("lg_u64", DPM, 0)
         A.s_cbranch_scc0(L_nodp)
         # ---- cold: wave-compacted DP records (emit_dp of kng_engine.hip; GPUCompute.h:96-105)
@@ -312,7 +329,6 @@ class Loop:
         # ---- the prefetch must have landed: everything issued behind it may still be in flight
         A.label(L_nodp)
         A.cur.schedule = False
-        n_after = 7 if self.dsplit else 8  # stores of this iteration issued behind the prefetch loads (x, y: 4; d: 1 or 2; products: 2)
         A.s_waitcnt(vmcnt=n_after, regs=NX + NY + [ND.sub(0, 2)] + ([] if self.dsplit else [ND.sub(2, 2)]) + self.NB)
         if copy_back:
             A.block("commit")
