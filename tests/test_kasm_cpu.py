@@ -129,7 +129,7 @@ def test_walk_loop_against_integer_model(case):
 
 def test_walk_loop_dp_overflow_is_counted_not_stored():
     """records beyond max_found are counted (the host reports them lost) but not written"""
-    jx, jy, jd = kwalk_emu.random_table(9, 40)
+    jx, jy, jd = kwalk_emu.random_table(109, 40)  # (not the model's seed: equal seeds put kangaroo 17 ON jump point 17, dx = 0)
     m = kwalk_emu.Model(64, 2, jx, jy, jd, dp_mask=0, seed=9)  # mask 0: every point is distinguished
     acc = m.pass0()
     h = kwalk_emu.Harness(m, True, max_found=50)
@@ -147,3 +147,44 @@ def test_generated_headers_are_current():
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", gen)], check=True, capture_output=True)
         after = open(path).read()
         assert before == after, f"{hdr} is stale: run tools/{gen}"
+
+
+def test_valu_flag_mode_is_a_superset_on_the_golden_vectors(golden):
+    """flag mode "valu" (the walk loop's default): the exactness conditions are not ORed one by one but bounded by a
+    running v_max3 / v_min3 over the words one of which must be within 1024 of 2^32 (resp. below 1024) for any condition to
+    hold.  Over every golden ModMulK1 / ModSub vector (edge-heavy: dropped carries, borrow ripples) a lane may differ from
+    the reference only when flagged -- for the plain fold and for the exact-tail form the loop uses for inv * dx."""
+    for exact_tail in (False, True):
+        A = kasm.Asm()
+        a = [A.v(f"a{i}", pinned=True) for i in range(8)]
+        b = [A.v(f"b{i}", pinned=True) for i in range(8)]
+        rare, k977, v977 = A.st("rare", 2, pinned=True), A.s("k977", pinned=True), A.v("v977", pinned=True)
+        shi, slo = A.s("shi", pinned=True), A.s("slo", pinned=True)
+        F = kfield.Field(A, k977, rare)
+        F.flag_mode = "valu"
+        A.block("A")
+        A.s_mov_b32(shi, (1 << 32) - kfield.Field.NEAR)
+        A.s_mov_b32(slo, kfield.Field.NEAR)
+        F.begin_flags("t", shi, slo)
+        prod = kfield.fe_mul(F, a, b, exact_tail=exact_tail)
+        diff = kfield.fe_sub(F, a, b, k977_v=v977)
+        F.end_flags("t")
+        A.keep(*prod, *diff, rare, k977)
+        kasm.schedule(A)
+        kasm.allocate(A, list(range(0, 160)), list(range(0, 64)))
+        assert not kasm.verify(A)
+        text = kasm.listing(A, comments=False)
+        ops = {"a": [r.phys for r in a], "b": [r.phys for r in b], "rare": rare[0].phys, "k977": k977.phys, "v977": v977.phys}
+        for name, ref, out in (("modmul", kfield.ref_mul, prod), ("modsub", kfield.ref_sub, diff)):
+            cases = [(int(x, 16) & ((1 << 256) - 1), int(y, 16) & ((1 << 256) - 1)) for x, y, _ in golden[name]]
+            got = _run_binary_op(text, dict(ops, r=[r.phys for r in out]), cases)
+            flagged = sum(r for _, r in got)
+            for (g, r), (x, y) in zip(got, cases):
+                assert r or g == ref(x, y), f"{name} {x:x} {y:x}"
+            assert flagged < len(cases) // 2, (name, flagged)
+        import random
+
+        rnd = random.Random(11)
+        rcases = [(rnd.getrandbits(256), rnd.getrandbits(256)) for _ in range(128)]
+        rgot = _run_binary_op(text, dict(ops, r=[r.phys for r in prod]), rcases)
+        assert all(not r and g == kfield.ref_mul(x, y) for (g, r), (x, y) in zip(rgot, rcases))  # random operands: never flagged

@@ -77,13 +77,20 @@ class Loop:
         self.CD, self.ND = q("cd"), q("nd")  # distance: (lo0, lo1, hi0, hi1); DSPLIT streams only the low pair
         self.F = kfield.Field(A, self.k977, self.rare)
         self.F.elide_first_carry = os.environ.get("KASM_ELIDE", "0") == "1"
+        self.F.flag_mode = os.environ.get("KASM_FLAGS", "valu")  # +1.7 % against "salu" (profiles/r03_ab_flags_valu.txt)
+        self.s_near_hi, self.s_near_lo = A.s("near_hi", pinned=True), A.s("near_lo", pinned=True)
         self.unroll = int(os.environ.get("KASM_UNROLL", "2"))
         # measurement builds only (WRONG results on purpose, see tools/r3_sensitivity.sh): comma list of
         #   nos      no traffic of the product planes S (the neighbour product is whatever the registers hold)
         #   nosA     ... in iteration A only           } together: the cost/benefit proxy of storing every OTHER
         #   plusmulA one extra product in iteration A  } prefix product (-32 B/jump, +1/2 multiplication per jump)
         #   nostore  x, y, d not written back
+        #   noglobal no global loads / stores inside the loop at all;  nolds: jump-table words taken from other registers
+        #   noflags  the exactness flags are not collected (no s_or of lane masks)
         self.abl = set(filter(None, os.environ.get("KASM_ABL", "").split(",")))
+        self.in_loop = False
+        if "noflags" in self.abl:
+            A.s_or_accum = lambda acc, m: None
 
     @staticmethod
     def limbs(quads):
@@ -91,11 +98,15 @@ class Loop:
 
     # ------------------------------------------------------------------------------------------------
     def load_fe(self, quads, voff, p0, p1, nt):
+        if "noglobal" in self.abl and self.in_loop:
+            return
         self.A.global_load(4, quads[0], voff, self.P[p0], nt=nt)
         self.A.global_load(4, quads[1], voff, self.P[p1], nt=nt)
 
     def load_d(self, quad, voff8):
         A = self.A
+        if "noglobal" in self.abl and self.in_loop:
+            return
         A.global_load(2, quad.sub(0, 2), voff8, self.P["dlo"])
         if not self.dsplit:
             A.global_load(2, quad.sub(2, 2), voff8, self.P["dhi"])
@@ -124,6 +135,8 @@ class Loop:
         A.s_mov_b32(self.k977, 977)
         A.v_mov_b32(self.v977, 977)
         A.s_mov_b64(self.rare, 0)
+        A.s_mov_b32(self.s_near_hi, (1 << 32) - kfield.Field.NEAR)
+        A.s_mov_b32(self.s_near_lo, kfield.Field.NEAR)
         for d, s_ in zip(self.limbs(self.ACCq), self.ACCop):
             A.v_mov_b32(d, s_)
         A.s_waitcnt(lgkmcnt=0, regs=[self.planes, self.dpblk])
@@ -149,6 +162,7 @@ class Loop:
         A.s_waitcnt(vmcnt=0, regs=self.CX + self.CY + [self.CD] + self.NB)
         # ================= loop =================
         L_loop = ".Lkw_loop_%="
+        self.in_loop = True
         if unroll == 1:
             self.iteration("a", set0, set1, L_loop, L_loop, L_exit, copy_back=True)
         else:
@@ -185,6 +199,8 @@ class Loop:
         A.s_mov_b64(self.rare, 0)
         # ---------------- block A: everything up to the exactness check (scheduled as one graph)
         A.block("A")
+        if F.flag_mode == "valu":
+            F.begin_flags(T("fl"), self.s_near_hi, self.s_near_lo)
         voffn = A.v(T("voffn")) if copy_back else nxt["voff"]
         voffnn, voffn8 = A.v(T("voffnn")), A.v(T("voffn8"))
         A.v_add_u32(voffn, s1, voff)
@@ -200,14 +216,17 @@ class Loop:
         A.v_lshl_add_u32(laddr, jidx, 3, self.ldstab)
         JX, JY = [A.vt(T("jx0"), 4), A.vt(T("jx1"), 4)], [A.vt(T("jy0"), 4), A.vt(T("jy1"), 4)]
         JD = A.vt(T("jd"), 4)
-        A.ds_read2_b64(JX[0], laddr, 0, 32)
-        A.ds_read2_b64(JX[1], laddr, 64, 96)
-        A.ds_read2_b64(JY[0], laddr, 128, 160)
-        A.ds_read2_b64(JY[1], laddr, 192, 224)
-        A.ds_read_b64(JD.sub(0, 2), laddr, 2048)
-        if not self.dsplit:
-            A.ds_read_b64(JD.sub(2, 2), laddr, 2048 + 256)
-        A.s_waitcnt(lgkmcnt=0, regs=JX + JY + [JD.sub(0, 2)] + ([] if self.dsplit else [JD.sub(2, 2)]))
+        if "nolds" in self.abl:
+            JX, JY, JD = CY, CX, CD
+        else:
+            A.ds_read2_b64(JX[0], laddr, 0, 32)
+            A.ds_read2_b64(JX[1], laddr, 64, 96)
+            A.ds_read2_b64(JY[0], laddr, 128, 160)
+            A.ds_read2_b64(JY[1], laddr, 192, 224)
+            A.ds_read_b64(JD.sub(0, 2), laddr, 2048)
+            if not self.dsplit:
+                A.ds_read_b64(JD.sub(2, 2), laddr, 2048 + 256)
+            A.s_waitcnt(lgkmcnt=0, regs=JX + JY + [JD.sub(0, 2)] + ([] if self.dsplit else [JD.sub(2, 2)]))
         jx, jy = self.limbs(JX), self.limbs(JY)
         nb = self.limbs(self.NB)
         # P1: invk = inv * nb ; dx, dy ; P2: inv' = inv * dx
@@ -219,7 +238,7 @@ class Loop:
             self.load_fe(self.NB, voffnn, "s01", "s23", False)
         dx = kfield.fe_sub(F, cx, jx, tag=T("dx"), k977_v=self.v977)
         dy = kfield.fe_sub(F, cy, jy, tag=T("dy"), k977_v=self.v977)
-        INVn = kfield.fe_mul(F, INV, dx, out=nxt["INV"], tag=T("p2"))
+        INVn = kfield.fe_mul(F, INV, dx, out=nxt["INV"], tag=T("p2"), exact_tail=True)  # = 1 (mod p) behind the last kangaroo
         if "plusmulA" in self.abl and tag == "a":
             XM = kfield.fe_mul(F, dx, dy, tag=T("px"))  # measurement only: the extra product of the every-other-product form
             dy = kfield.fe_sub(F, XM, jy, tag=T("dyx"), k977_v=self.v977)  # (kept alive by feeding P3)
@@ -250,9 +269,12 @@ class Loop:
         A.v_and_b32(jidx2, 31, RX[0])
         A.v_lshl_add_u32(laddr2, jidx2, 3, self.ldstab)
         JX2 = [A.vt(T("jxn0"), 4), A.vt(T("jxn1"), 4)]
-        A.ds_read2_b64(JX2[0], laddr2, 0, 32)
-        A.ds_read2_b64(JX2[1], laddr2, 64, 96)
-        A.s_waitcnt(lgkmcnt=0, regs=JX2)
+        if "nolds" in self.abl:
+            JX2 = CY
+        else:
+            A.ds_read2_b64(JX2[0], laddr2, 0, 32)
+            A.ds_read2_b64(JX2[1], laddr2, 64, 96)
+            A.s_waitcnt(lgkmcnt=0, regs=JX2)
         dx2 = kfield.fe_sub(F, RX, self.limbs(JX2), tag=T("dx2"), k977_v=self.v977)
         ACCq = self.ACCq
         ACCn = kfield.fe_mul(F, self.limbs(ACCq), dx2, out=self.limbs(ACCq), tag=T("p6"))  # in place (write-after-read ordered)
@@ -263,6 +285,8 @@ class Loop:
         A.v_or_b32(t1, t1, t2)
         DPM = A.st(T("dpm"), 2)
         A.v_cmp_eq_u32(DPM, 0, t1)
+        if F.flag_mode == "valu":
+            F.end_flags(T("fl"))
         # everything the stores and the commit need must be complete here
         A.keep(*INVn, *RX, *RY, *ACCn, *DN.regs[:2 if self.dsplit else 4], DPM)
         A.s_cmp("lg_u64", self.rare, 0)
@@ -272,7 +296,7 @@ class Loop:
         voff8 = A.v(T("voff8"))
         A.v_lshrrev_b32(voff8, 1, voff)
         n_after = 0  # stores of this iteration issued behind the prefetch loads
-        if "nostore" not in self.abl:
+        if "nostore" not in self.abl and "noglobal" not in self.abl:
             A.global_store(4, voff, RXq[0], self.P["x01"], nt=True)
             A.global_store(4, voff, RXq[1], self.P["x23"], nt=True)
             A.global_store(4, voff, RYq[0], self.P["y01"], nt=True)
@@ -282,7 +306,7 @@ class Loop:
             if not self.dsplit:
                 A.global_store(2, voff8, DN.sub(2, 2), self.P["dhi"])
                 n_after += 1
-        if not no_s:
+        if not no_s and "noglobal" not in self.abl:
             A.global_store(4, voff, ACCq[0], self.P["s01"])
             A.global_store(4, voff, ACCq[1], self.P["s23"])
             n_after += 2

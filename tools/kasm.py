@@ -129,7 +129,7 @@ def fmt_operand(x):
 
 class Ins:
     __slots__ = ("op", "args", "defs", "uses", "cls", "mods", "comment", "order", "label", "target", "vm", "barrier",
-                 "accum")
+                 "accum", "asap")
 
     def __init__(self, op, args=(), defs=(), uses=(), cls="valu", mods="", comment="", label=None, target=None, vm=None,
                  barrier=False):
@@ -141,6 +141,7 @@ class Ins:
         self.barrier = barrier  # scheduling barrier (keeps its place)
         self.order = 0
         self.accum = None  # register (tuple) this instruction ORs into: such instructions commute among themselves
+        self.asap = False  # issue as soon as ready whatever the critical path says (it ends live ranges and starts none)
 
     def text(self):
         if self.cls == "label":
@@ -261,6 +262,19 @@ class Asm:
 
     def v_lshl_add_u32(self, d, x, sh, y, **k):
         return self._v2("v_lshl_add_u32", d, x, sh, y, **k)
+
+    def v_accum3(self, op, acc, x, y):
+        """acc = op(acc, x, y) for a commutative, associative op (v_max3_u32 / v_min3_u32): accumulations into the same
+        register commute, like s_or_accum -- the scheduler orders them only against ordinary accesses of `acc`"""
+        ins = self.emit(Ins(op, [acc, acc, x, y], defs=[], uses=[x, y, EXEC]))
+        ins.accum = acc
+        return ins
+
+    def v_cmp_le_u32(self, sd, x, y, **k):
+        return self._v2("v_cmp_le_u32_e64", sd, x, y, **k)
+
+    def v_cmp_gt_u32(self, sd, x, y, **k):
+        return self._v2("v_cmp_gt_u32_e64", sd, x, y, **k)
 
     def v_cmp_eq_u32(self, sd, x, y, **k):
         return self._v2("v_cmp_eq_u32_e64", sd, x, y, **k)
@@ -435,6 +449,10 @@ WS_STORE_DATA_TO_VALU_WRITE = 2  # 128-bit (and 96-bit) store data
 WS_VALU_VGPR_TO_READLANE = 1
 # not a hazard but a stall: an SALU instruction that reads an SGPR a VALU has just written waits for the VALU result
 SOFT_VALU_SGPR_TO_SALU = 6
+# issue slots the scheduler tries to put between a ds_read and the s_waitcnt that makes its data valid (a latency to hide,
+# not a hazard: 1 = wait right behind the read)
+import os as _os
+LDS_WAIT_SLOTS = int(_os.environ.get("KASM_LDSLAT", "128"))  # +0.7 % against 1 (profiles/r03_ab_flags_valu.txt)
 
 
 def _is_sgprish(r):
@@ -570,6 +588,8 @@ def schedule_block(block, hz, window=None, sgpr_limit=28, vgpr_limit=150):
                 w = 1
                 if ins[a].cls == "valu" and _is_sgprish(r):
                     w = {"valu": 3, "vmem_ld": 6, "vmem_st": 6, "lds": 6}.get(x.cls, 1)
+                if ins[a].cls == "lds" and x.cls == "wait" and r is not MEMTOK:
+                    w = LDS_WAIT_SLOTS  # the data is ~LDS_WAIT_SLOTS issue slots away: fill them instead of parking the wave
                 edge(a, i, w)
         for r in x.defs:
             if r in last_def:
@@ -639,7 +659,7 @@ def schedule_block(block, hz, window=None, sgpr_limit=28, vgpr_limit=150):
                 if hz.need(x, pos) > 0:
                     continue
                 soft = hz.need(x, pos, soft=True) > 0
-                key = (soft, -prio[i], i)
+                key = (soft, -(prio[i] + (10**6 if x.asap else 0)), i)
                 if best is None or key < best_key:
                     best, best_key = i, key
             if best is not None or not (over or over_v):
@@ -772,7 +792,9 @@ def allocate(asm, vpool, spool):
             groups[g] = (-1, len(prog))
     used = {"v": set(), "s": set()}
     for kind, pool in (("v", vpool), ("s", spool)):
-        items = sorted((se, id(g), g) for g, se in groups.items() if (g.regs[0].kind if isinstance(g, Tup) else g.kind) == kind)
+        # (ties in creation order -- never by id(): the generated text must not depend on where objects landed in memory)
+        items = sorted((se, (g.regs[0].uid if isinstance(g, Tup) else g.uid), g) for g, se in groups.items()
+                       if (g.regs[0].kind if isinstance(g, Tup) else g.kind) == kind)
         free = set(pool)
         active = []  # (end, regs)
         for (s, e), _, g in items:

@@ -274,6 +274,12 @@ class Emu:
     def op_v_and_or_b32(self, a, m, f):
         self._v(a, lambda x, y, z: (x & y) | z)
 
+    def op_v_max3_u32(self, a, m, f):
+        self._v(a, lambda x, y, z: max(x, y, z))
+
+    def op_v_min3_u32(self, a, m, f):
+        self._v(a, lambda x, y, z: min(x, y, z))
+
     def op_v_lshl_add_u32(self, a, m, f):
         self._v(a, lambda x, sh, y: (x << (sh & 31)) + y)
 
@@ -304,6 +310,12 @@ class Emu:
 
     def op_v_cmp_lt_u32(self, a, m, f):
         self._vcmp(a, lambda x, y: x < y)
+
+    def op_v_cmp_le_u32(self, a, m, f):
+        self._vcmp(a, lambda x, y: x <= y)
+
+    def op_v_cmp_gt_u32(self, a, m, f):
+        self._vcmp(a, lambda x, y: x > y)
 
     def op_v_cmp_ge_u32(self, a, m, f):
         self._vcmp(a, lambda x, y: x >= y)

@@ -32,6 +32,58 @@ class Field:
         # a column's first multiply-add starts from a carry-in below 2^36 and overflows 64 bits only when its product is
         # within 2^36 of 2^64 (~2^-28): flag it for the exact path instead of counting it with a v_addc
         self.elide_first_carry = False
+        # How the "short form not exact" conditions reach `rare`.
+        #   "salu": every carry-out that signals one is ORed into `rare` (one s_or_b64 per condition: 11 per fold, 2 per sub)
+        #   "valu": a SUPERSET of the conditions is tracked in two VGPRs instead -- every condition needs some word within
+        #           1024 of 2^32 (resp. below 1024), so a running v_max3_u32 / v_min3_u32 over those words and ONE
+        #           comparison each per iteration decide (begin_flags / end_flags).  5 VALU per fold and 1 per sub replace
+        #           11 + 2 scalar ORs, each of which stalls on the VALU-written lane masks it reads (profiles/r03_stalls.txt).
+        #           The price: ~1.2e-3 of the wave-iterations take the exact path instead of ~0.6e-3.
+        self.flag_mode = "salu"
+        self.mx = self.mn = None
+
+    # ---- "valu" flag mode: per scheduled region, begin_flags() ... arithmetic ... end_flags()
+    NEAR = 1024  # every flagged condition implies a word >= 2^32 - NEAR (max side) or < NEAR (min side); 977 + 1 < NEAR
+
+    def begin_flags(self, tag, s_hi, s_lo):
+        """s_hi / s_lo: SGPRs holding 2^32 - NEAR and NEAR (VOP3 takes no literal on gfx9)"""
+        A = self.A
+        self.mx, self.mn = A.v(f"{tag}mx"), A.v(f"{tag}mn")
+        self.s_hi, self.s_lo = s_hi, s_lo
+        A.v_mov_b32(self.mx, 0)
+        A.v_mov_b32(self.mn, -1)
+
+    def end_flags(self, tag):
+        """ORs the two verdicts into `rare`"""
+        A = self.A
+        f1, f2 = A.st(f"{tag}fmx", 2), A.st(f"{tag}fmn", 2)
+        A.v_cmp_le_u32(f1, self.s_hi, self.mx)  # some tracked word >= 2^32 - NEAR
+        A.v_cmp_gt_u32(f2, self.s_lo, self.mn)  # some tracked word < NEAR
+        A.s_or_accum(self.rare, f1)
+        A.s_or_accum(self.rare, f2)
+        self.mx = self.mn = None
+
+    def near_max(self, words, tag):
+        """track words of which one must be within NEAR of 2^32 for a condition to hold"""
+        A = self.A
+        words = list(words)
+        loc = None
+        # local tree first (independent of the running maximum), one link into the running maximum at the end
+        while len(words) > 2 or (loc is not None and len(words) > 1):
+            if loc is None:
+                loc = A.v(self.uid(f"{tag}lm"))
+                A._v2("v_max3_u32", loc, words[0], words[1], words[2]).asap = True
+                words = words[3:]
+            else:
+                nl = A.v(self.uid(f"{tag}lm"))
+                A._v2("v_max3_u32", nl, loc, words[0], words[1]).asap = True
+                loc, words = nl, words[2:]
+        rest = ([loc] if loc is not None else []) + words
+        assert 1 <= len(rest) <= 2
+        A.v_accum3("v_max3_u32", self.mx, rest[0], rest[-1]).asap = True
+
+    def near_min(self, a, b):
+        self.A.v_accum3("v_min3_u32", self.mn, a, b).asap = True
 
     def uid(self, stem):
         self.n += 1
@@ -146,7 +198,7 @@ def fe_sqr(F: Field, a, out=None, tag="q"):
     return fold(F, comba_sqr(F, a, tag), out, tag)
 
 
-def fold(F: Field, PW, out=None, tag="f"):
+def fold(F: Field, PW, out=None, tag="f", exact_tail=False):
     """PW: 8 pairs (w[2m], w[2m+1]).  out: optional list of 8 Regs to receive the result (out[0], out[1] must be an
     even-aligned pair).  Returns the 8 result registers."""
     A = F.A
@@ -188,13 +240,25 @@ def fold(F: Field, PW, out=None, tag="f"):
         A.v_mov_b32(out[0], r01[0], comment="r0")
     A.v_addc_co_u32(out[2], C2, s2, 0, C2, comment="r2; carry-out leaves limb 2 only when it was all ones")
     flags.append(C2)
-    for m in flags:
-        A.s_or_accum(F.rare, m)
+    if F.flag_mode == "valu":
+        # every condition above needs one of these words within 1024 of 2^32: the odd words of W (E_j: w[2j+1], O_j and the
+        # top carry: w[9+2j]), s1 (the second fold's MAD) and s2 (the ripple beyond limb 2) -- see the notes at each flag
+        # exact_tail: a product that is congruent to a small number (inv * dx = 1 behind the last kangaroo of a pass) has
+        # S = p + small, i.e. s1.. all ones in EVERY lane: its two tail conditions keep their exact flags
+        if exact_tail:
+            F.near_max([PW[m].hi for m in range(8)], tag)
+            A.s_or_accum(F.rare, c1)
+            A.s_or_accum(F.rare, C2)
+        else:
+            F.near_max([PW[m].hi for m in range(8)] + [s[1], s2], tag)
+    else:
+        for m in flags:
+            A.s_or_accum(F.rare, m)
     return out
 
 
-def fe_mul(F: Field, a, b, out=None, tag="m"):
-    return fold(F, comba(F, a, b, tag), out, tag)
+def fe_mul(F: Field, a, b, out=None, tag="m", exact_tail=False):
+    return fold(F, comba(F, a, b, tag), out, tag, exact_tail)
 
 
 def fe_sub(F: Field, x, y, out=None, tag="s", k977_v=None):
@@ -216,8 +280,11 @@ def fe_sub(F: Field, x, y, out=None, tag="s", k977_v=None):
     D, E = A.st(F.uid("sd"), 2), A.st(F.uid("se"), 2)
     A.v_sub_co_u32(out[0], D, t[0], q0)
     A.v_subb_co_u32(out[1], E, t[1], 0, B)
-    A.s_or_accum(F.rare, D)
-    A.s_or_accum(F.rare, E)
+    if F.flag_mode == "valu":
+        F.near_min(t[0], t[1])  # D needs t0 < 977, E needs t1 = 0
+    else:
+        A.s_or_accum(F.rare, D)
+        A.s_or_accum(F.rare, E)
     return out
 
 
