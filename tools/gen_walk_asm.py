@@ -89,6 +89,9 @@ class Loop:
         #   noflags  the exactness flags are not collected (no s_or of lane masks)
         self.abl = set(filter(None, os.environ.get("KASM_ABL", "").split(",")))
         self.in_loop = False
+        # cache-hint experiments (default: x, y stream with nt; products and distances plain): letters of KASM_NT flip one each
+        #   S product loads nt   s product stores nt   d distance loads + stores nt   X x/y loads plain   x x/y stores plain
+        self.nt = os.environ.get("KASM_NT", "")
         if "noflags" in self.abl:
             A.s_or_accum = lambda acc, m: None
 
@@ -97,19 +100,19 @@ class Loop:
         return [r for qd in quads for r in qd.regs]
 
     # ------------------------------------------------------------------------------------------------
-    def load_fe(self, quads, voff, p0, p1, nt):
+    def load_fe(self, quads, voff, p0, p1, nt, asap=False):
         if "noglobal" in self.abl and self.in_loop:
             return
-        self.A.global_load(4, quads[0], voff, self.P[p0], nt=nt)
-        self.A.global_load(4, quads[1], voff, self.P[p1], nt=nt)
+        self.A.global_load(4, quads[0], voff, self.P[p0], nt=nt).asap = asap
+        self.A.global_load(4, quads[1], voff, self.P[p1], nt=nt).asap = asap
 
-    def load_d(self, quad, voff8):
+    def load_d(self, quad, voff8, asap=False):
         A = self.A
         if "noglobal" in self.abl and self.in_loop:
             return
-        A.global_load(2, quad.sub(0, 2), voff8, self.P["dlo"])
+        A.global_load(2, quad.sub(0, 2), voff8, self.P["dlo"], nt="d" in self.nt).asap = asap
         if not self.dsplit:
-            A.global_load(2, quad.sub(2, 2), voff8, self.P["dhi"])
+            A.global_load(2, quad.sub(2, 2), voff8, self.P["dhi"], nt="d" in self.nt).asap = asap
 
     def set_one(self, quads):
         A = self.A
@@ -203,12 +206,13 @@ class Loop:
             F.begin_flags(T("fl"), self.s_near_hi, self.s_near_lo)
         voffn = A.v(T("voffn")) if copy_back else nxt["voff"]
         voffnn, voffn8 = A.v(T("voffnn")), A.v(T("voffn8"))
-        A.v_add_u32(voffn, s1, voff)
-        A.v_add_u32(voffnn, s2, voffn)
-        A.v_lshrrev_b32(voffn8, 1, voffn)
-        self.load_fe(NX, voffn, "x01", "x23", True)
-        self.load_fe(NY, voffn, "y01", "y23", True)
-        self.load_d(ND, voffn8)
+        early = os.environ.get("KASM_EARLYLD", "0") == "1"  # the prefetch at the very top of the iteration, not where the critical path leaves room
+        A.v_add_u32(voffn, s1, voff).asap = early
+        A.v_add_u32(voffnn, s2, voffn).asap = early
+        A.v_lshrrev_b32(voffn8, 1, voffn).asap = early
+        self.load_fe(NX, voffn, "x01", "x23", "X" not in self.nt, asap=early)
+        self.load_fe(NY, voffn, "y01", "y23", "X" not in self.nt, asap=early)
+        self.load_d(ND, voffn8, asap=early)
         # jump table entry j = x & 31
         cx, cy = self.limbs(CX), self.limbs(CY)
         jidx, laddr = A.v(T("jidx")), A.v(T("laddr"))
@@ -235,7 +239,7 @@ class Loop:
         # dependencies place the loads behind P1's last multiply): no second register set, no moves
         no_s = "nos" in self.abl or ("nosA" in self.abl and tag == "a")
         if not no_s:
-            self.load_fe(self.NB, voffnn, "s01", "s23", False)
+            self.load_fe(self.NB, voffnn, "s01", "s23", "S" in self.nt, asap=os.environ.get("KASM_EARLYLD", "0") == "1")
         dx = kfield.fe_sub(F, cx, jx, tag=T("dx"), k977_v=self.v977)
         dy = kfield.fe_sub(F, cy, jy, tag=T("dy"), k977_v=self.v977)
         INVn = kfield.fe_mul(F, INV, dx, out=nxt["INV"], tag=T("p2"), exact_tail=True)  # = 1 (mod p) behind the last kangaroo
@@ -297,18 +301,18 @@ class Loop:
         A.v_lshrrev_b32(voff8, 1, voff)
         n_after = 0  # stores of this iteration issued behind the prefetch loads
         if "nostore" not in self.abl and "noglobal" not in self.abl:
-            A.global_store(4, voff, RXq[0], self.P["x01"], nt=True)
-            A.global_store(4, voff, RXq[1], self.P["x23"], nt=True)
-            A.global_store(4, voff, RYq[0], self.P["y01"], nt=True)
-            A.global_store(4, voff, RYq[1], self.P["y23"], nt=True)
-            A.global_store(2, voff8, DN.sub(0, 2), self.P["dlo"])
+            A.global_store(4, voff, RXq[0], self.P["x01"], nt="x" not in self.nt)
+            A.global_store(4, voff, RXq[1], self.P["x23"], nt="x" not in self.nt)
+            A.global_store(4, voff, RYq[0], self.P["y01"], nt="x" not in self.nt)
+            A.global_store(4, voff, RYq[1], self.P["y23"], nt="x" not in self.nt)
+            A.global_store(2, voff8, DN.sub(0, 2), self.P["dlo"], nt="d" in self.nt)
             n_after += 5
             if not self.dsplit:
-                A.global_store(2, voff8, DN.sub(2, 2), self.P["dhi"])
+                A.global_store(2, voff8, DN.sub(2, 2), self.P["dhi"], nt="d" in self.nt)
                 n_after += 1
         if not no_s and "noglobal" not in self.abl:
-            A.global_store(4, voff, ACCq[0], self.P["s01"])
-            A.global_store(4, voff, ACCq[1], self.P["s23"])
+            A.global_store(4, voff, ACCq[0], self.P["s01"], nt="s" in self.nt)
+            A.global_store(4, voff, ACCq[1], self.P["s23"], nt="s" in self.nt)
             n_after += 2
         A.s_cmp("lg_u64", DPM, 0)
         A.s_cbranch_scc0(L_nodp)
