@@ -406,16 +406,17 @@ def test_dp_ring_delivers_the_same_records(kng, orc, use_asm, ring):
     small.close()
 
 
-@pytest.mark.parametrize("dsplit", [1, 0])
-def test_bench_config_total_parity(kng, orc, dsplit):
+@pytest.mark.parametrize("rp,dp,dsplit", [(80, 14, 1), (80, 14, 0), (109, 25, 0)])
+def test_bench_config_total_parity(kng, orc, rp, dp, dsplit):
     """BASELINE.md 3's gate taken literally, at the bench configuration (80-bit range, grid 512x128 = 2^23 kangaroos,
     auto DP 14, default kernel): after one launch ALL 2^23 (x, y, d) triples and the COMPLETE distinguished-point
-    multiset equal the oracle's (walked over a thread pool: kangaroos are independent).  Both distance layouts."""
+    multiset equal the oracle's (walked over a thread pool: kangaroos are independent).  Both distance layouts, and the
+    puzzle-#110 table (BASELINE configs[3]: 109-bit range, DP 25, jump distances ~2^54) at the same herd."""
     import kangaroo_amd.hostlib as hl
 
-    rp, gx, gy, dp = 80, 512, 128, 14
+    gx, gy = 512, 128
     n = gx * gy * 128
-    _, kx, ky = hl.pubkey((1 << 79) + 0xC0FFEE123456789ABCD)
+    _, kx, ky = hl.pubkey((1 << (rp - 1)) + 0xC0FFEE123456789ABCD)
     jd, jx, jy, _ = hl.jump_table(rp)
     ojd, ojx, ojy, _ = orc.jump_table(rp)
     assert np.array_equal(jd, ojd) and np.array_equal(jx, ojx) and np.array_equal(jy, ojy)
@@ -432,7 +433,8 @@ def test_bench_config_total_parity(kng, orc, dsplit):
         x1, y1, d1 = eng.GetKangaroos(raw=True)
     want = orc.walk_parallel(x0, y0, d0, 64, jd, jx, jy, mask)
     assert np.array_equal(x1, x0) and np.array_equal(y1, y0) and np.array_equal(d1, d0)  # x0.. now hold the oracle's end state
-    assert len(got) == len(want) and 0.9 * (n * 64 >> dp) < len(got) < 1.1 * (n * 64 >> dp)
+    mean = (n * 64) >> dp
+    assert len(got) == len(want) and mean - 6 * mean**0.5 - 1 < len(got) < mean + 6 * mean**0.5 + 1
 
     def canon(r):  # order by (kidx, d low word): a kangaroo may hit two distinguished points in one launch
         o = np.lexsort((r["d"][:, 0], r["kidx"]))
@@ -734,6 +736,65 @@ def test_distance_low_word_streaming_vs_oracle(kng, orc, share):
     eng = kng.GPUEngine(grid[0], grid[1], 0, 1 << 17, share=share, group=8, dsplit=1)
     eng.SetParams(mask, jd, jx, jy)
     assert eng.get_option("dsplit") == 1
+    eng.SetKangaroos(x, y, d)
+    ox, oy, od = x.copy(), y.copy(), d.copy()
+    for _ in range(3):
+        eng.callKernel()
+        eng.wait()
+        got = eng.drain(raw=True)
+        want, total = orc.walk(ox, oy, od, 64, jd, jx, jy, mask, dp_cap=1 << 22)
+        key = lambda r: (int(r["kidx"]), tuple(int(v) for v in r["x"]), tuple(int(v) for v in r["d"]))  # noqa: E731
+        assert len(got) == total and sorted(map(key, got)) == sorted(map(key, want))
+        gx, gy, gd = eng.GetKangaroos(raw=True)
+        assert np.array_equal(gx, ox) and np.array_equal(gy, oy) and np.array_equal(gd, od)
+    eng.close()
+
+
+@pytest.mark.parametrize("share,dsplit", [(8, 1), (8, 0), (1, 1)])
+def test_exact_path_exits_of_the_scheduled_loop(kng, orc, share, dsplit):
+    """The scheduled asm loop leaves an iteration to the general arithmetic (walk_core) when its short forms may not be
+    exact; since round 3 it decides that from a SUPERSET of the conditions (a word below 1024 in a difference, a word within
+    1024 of 2^32 in a product).  A herd seeded with kangaroos that raise those flags at every position of a pass -- x a few
+    units beside its own jump point (tiny dx: difference words below 1024), x and y with limbs of all ones (borrow ripples,
+    products with words near 2^32), first / middle / last of a lane's batch, several neighbours in a row -- must still
+    equal the oracle bit for bit, DP multiset included, over three launches."""
+    grid = (2, 4)
+    n = grid[0] * grid[1] * 128
+    rp = 72
+    x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=777)
+    jd, jx, jy, _ = orc.jump_table(rp)
+    if not dsplit:
+        jd = jd.copy()
+        jd[:, 0] |= np.uint64(1 << 55)  # distances the engine will not stream low-word-only
+    rng = np.random.default_rng(5)
+    d = np.zeros((n, 2), np.uint64)  # raw device distances (no wild offset set: Set/Get pass them through)
+    d[:, 0] = rng.integers(0, (1 << 63), size=n, dtype=np.uint64)
+    d[:, 1] = rng.integers(0, 1 << 40, size=n, dtype=np.uint64)
+    x, y = x.copy(), y.copy()
+    jxi = array_to_ints(jx)
+    G, L = 8, n // 8  # group 8: kangaroo g of lane t is index g * L + t
+    crafted = 0
+    for t_ in range(0, L, 3):
+        for g in {0: (0,), 1: (G - 1,), 2: (3, 4), 3: (0, 1, 2, G - 1)}[(t_ // 3) % 4]:
+            idx = g * L + t_
+            kind = (idx // 7) % 3
+            if kind == 0:  # a few units beside the jump point its own low bits select: dx = delta < 1024
+                j = int(rng.integers(0, 32))
+                delta = ((j - (jxi[j] & 31)) % 32) + 32 * int(rng.integers(1, 30))
+                x[idx] = ints_to_array([(jxi[j] + delta) & ((1 << 256) - 1)], 4)[0]
+                assert (int(x[idx][0]) & 31) == j
+            elif kind == 1:  # limbs of all ones: every borrow ripples, products get words within 1024 of 2^32
+                x[idx] = np.array([0xFFFFFFFFFFFFFC00 | int(rng.integers(0, 1024)), (1 << 64) - 1, (1 << 64) - 1, 0xFFFFFFFEFFFFFFFF], np.uint64)
+                y[idx] = np.array([(1 << 64) - 1, 0xFFFFFFFF00000000, (1 << 64) - 1, (1 << 64) - 1], np.uint64)
+            else:  # small values: differences wrap, low words of everything near zero
+                x[idx] = np.array([int(rng.integers(1, 1 << 20)), 0, 0, 0], np.uint64)
+                y[idx] = np.array([int(rng.integers(1, 1 << 20)), 0, 0, 0], np.uint64)
+            crafted += 1
+    assert crafted > n // 40
+    mask = orc.dp_mask(4)
+    eng = kng.GPUEngine(grid[0], grid[1], 0, 1 << 17, share=share, group=G, asm=1)
+    eng.SetParams(mask, jd, jx, jy)
+    assert eng.get_option("dsplit") == dsplit and eng.get_option("asm") == 1
     eng.SetKangaroos(x, y, d)
     ox, oy, od = x.copy(), y.copy(), d.copy()
     for _ in range(3):
