@@ -154,7 +154,7 @@ def test_valu_flag_mode_is_a_superset_on_the_golden_vectors(golden):
     running v_max3 / v_min3 over the words one of which must be within 1024 of 2^32 (resp. below 1024) for any condition to
     hold.  Over every golden ModMulK1 / ModSub vector (edge-heavy: dropped carries, borrow ripples) a lane may differ from
     the reference only when flagged -- for the plain fold and for the exact-tail form the loop uses for inv * dx."""
-    for exact_tail in (False, True):
+    for exact_tail, elide in ((False, False), (True, False), (False, True), (True, True)):
         A = kasm.Asm()
         a = [A.v(f"a{i}", pinned=True) for i in range(8)]
         b = [A.v(f"b{i}", pinned=True) for i in range(8)]
@@ -162,6 +162,7 @@ def test_valu_flag_mode_is_a_superset_on_the_golden_vectors(golden):
         shi, slo = A.s("shi", pinned=True), A.s("slo", pinned=True)
         F = kfield.Field(A, k977, rare)
         F.flag_mode = "valu"
+        F.elide_first_carry = elide  # a column's first carry dropped: its superset is "a0 or b7 within 1024 of 2^32"
         A.block("A")
         A.s_mov_b32(shi, (1 << 32) - kfield.Field.NEAR)
         A.s_mov_b32(slo, kfield.Field.NEAR)
@@ -185,6 +186,13 @@ def test_valu_flag_mode_is_a_superset_on_the_golden_vectors(golden):
         import random
 
         rnd = random.Random(11)
+        # first-carry corner: both first factors of a column within 10 of 2^32 (a0 with b_k, a_k with b7), all limbs large
+        M = (1 << 256) - 1
+        edge = [((M - rnd.getrandbits(3)) & M, (M - (rnd.getrandbits(3) << 224)) & M) for _ in range(32)]
+        edge += [(((1 << 32) - 1 - rnd.getrandbits(3)) | (rnd.getrandbits(224) << 32), M - rnd.getrandbits(200)) for _ in range(32)]
+        egot = _run_binary_op(text, dict(ops, r=[r.phys for r in prod]), edge)
+        assert all(r or g == kfield.ref_mul(x, y) for (g, r), (x, y) in zip(egot, edge))
+        assert not elide or sum(r for _, r in egot) == len(edge)  # a0 / b7 within 1024 of 2^32: always flagged when elided
         rcases = [(rnd.getrandbits(256), rnd.getrandbits(256)) for _ in range(128)]
         rgot = _run_binary_op(text, dict(ops, r=[r.phys for r in prod]), rcases)
         assert all(not r and g == kfield.ref_mul(x, y) for (g, r), (x, y) in zip(rgot, rcases))  # random operands: never flagged

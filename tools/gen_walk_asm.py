@@ -76,7 +76,7 @@ class Loop:
         self.ACCq = [q("acc0"), q("acc1")]
         self.CD, self.ND = q("cd"), q("nd")  # distance: (lo0, lo1, hi0, hi1); DSPLIT streams only the low pair
         self.F = kfield.Field(A, self.k977, self.rare)
-        self.F.elide_first_carry = os.environ.get("KASM_ELIDE", "0") == "1"
+        self.F.elide_first_carry = os.environ.get("KASM_ELIDE", "1") == "1"  # +2.5 % under the VGPR flags (profiles/r03_ab_elide.txt); -0.7 % when it cost a scalar OR (round 2)
         self.F.flag_mode = os.environ.get("KASM_FLAGS", "valu")  # +1.7 % against "salu" (profiles/r03_ab_flags_valu.txt)
         self.s_near_hi, self.s_near_lo = A.s("near_hi", pinned=True), A.s("near_lo", pinned=True)
         self.unroll = int(os.environ.get("KASM_UNROLL", "2"))

@@ -41,6 +41,7 @@ class Field:
         #           The price: ~1.2e-3 of the wave-iterations take the exact path instead of ~0.6e-3.
         self.flag_mode = "salu"
         self.mx = self.mn = None
+        self.pending_near_max = []  # words comba() wants tracked with its product's fold (first-carry elision)
 
     # ---- "valu" flag mode: per scheduled region, begin_flags() ... arithmetic ... end_flags()
     NEAR = 1024  # every flagged condition implies a word >= 2^32 - NEAR (max side) or < NEAR (min side); 977 + 1 < NEAR
@@ -115,10 +116,16 @@ def comba(F: Field, a, b, tag="m"):
         for n_, (i, j) in enumerate(terms):
             # column 1 starts from X0 < 2^32: a*b + X0 <= 2^64 - 2^32, its first product cannot overflow at all
             first_safe = n_ == 0 and (k == 1 or F.elide_first_carry)
-            c = A.st(F.uid("c"), 2) if can_overflow and not (n_ == 0 and k == 1) else DUMMY
+            elided = can_overflow and n_ == 0 and k > 1 and F.elide_first_carry
+            c = A.st(F.uid("c"), 2) if can_overflow and not (n_ == 0 and k == 1) and not (elided and F.flag_mode == "valu") else DUMMY
             A.v_mad_u64_u32(acc, c, a[i], b[j], addend if n_ == 0 else acc, comment=f"a{i}*b{j}")
-            if can_overflow and n_ == 0 and k > 1 and F.elide_first_carry:
-                A.s_or_accum(F.rare, c)
+            if elided:
+                # the first product of a column starts from (carry word, carry count) < 9 * 2^32: it overflows 64 bits only when
+                # BOTH factors are within 10 of 2^32.  The column's first factors are a0 (k <= 7) or b7 (k > 7).
+                if F.flag_mode == "valu":
+                    F.pending_near_max = [a[0], b[7]]  # fold() tracks them with the product's other words
+                else:
+                    A.s_or_accum(F.rare, c)
             elif can_overflow and not first_safe:
                 carries.append(c)
         if carries:
@@ -157,10 +164,15 @@ def comba_sqr(F: Field, a, tag="q"):
         can_overflow = k >= 3
         carries = []
         for n_, (i, j) in enumerate(terms):
-            c = A.st(F.uid("c"), 2) if can_overflow else DUMMY
+            elided = can_overflow and n_ == 0 and F.elide_first_carry
+            c = A.st(F.uid("c"), 2) if can_overflow and not (elided and F.flag_mode == "valu") else DUMMY
             A.v_mad_u64_u32(acc, c, a[i], a[j], addend if n_ == 0 else acc, comment=f"a{i}*a{j}")
-            if can_overflow and n_ == 0 and F.elide_first_carry:
-                A.s_or_accum(F.rare, c)
+            if elided:
+                # as in comba(): the column's first product a_i * a_j has i = 0 (k <= 7) or j = 7 (k > 7)
+                if F.flag_mode == "valu":
+                    F.pending_near_max = [a[0], a[7]]
+                else:
+                    A.s_or_accum(F.rare, c)
             elif can_overflow:
                 carries.append(c)
         if can_overflow:
@@ -245,12 +257,13 @@ def fold(F: Field, PW, out=None, tag="f", exact_tail=False):
         # top carry: w[9+2j]), s1 (the second fold's MAD) and s2 (the ripple beyond limb 2) -- see the notes at each flag
         # exact_tail: a product that is congruent to a small number (inv * dx = 1 behind the last kangaroo of a pass) has
         # S = p + small, i.e. s1.. all ones in EVERY lane: its two tail conditions keep their exact flags
+        extra, F.pending_near_max = F.pending_near_max, []
         if exact_tail:
-            F.near_max([PW[m].hi for m in range(8)], tag)
+            F.near_max([PW[m].hi for m in range(8)] + extra, tag)
             A.s_or_accum(F.rare, c1)
             A.s_or_accum(F.rare, C2)
         else:
-            F.near_max([PW[m].hi for m in range(8)] + [s[1], s2], tag)
+            F.near_max([PW[m].hi for m in range(8)] + [s[1], s2] + extra, tag)
     else:
         for m in flags:
             A.s_or_accum(F.rare, m)
