@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run each ablated build (tools/ablate.py) -- or any command -- while sampling package power and GFX clock.
+"""Run each ablated build (build/abl/<name>/, round 2) -- or any command (tools/r3_sensitivity.sh, tools/r3_stalls.sh) -- while sampling package power and GFX clock.
 
 usage (on the GPU box): python tools/ablate_run.py [--launches 160] [name ...]
        python tools/ablate_run.py --cmd "./tools/mem_power_probe 0 0 5" --cmd "./tools/mem_power_probe 1 0 5"
