@@ -447,6 +447,7 @@ def main():
             counts["lost"] += eng.lastLost
         eng.wait()
         kernel_ms.append(eng.last_kernel_ms())
+        counts["exits"] = counts.get("exits", 0) + eng.get_option("exact_exits")
 
     def finish():
         counts["dps"] += len(eng.drain(raw=True))
@@ -480,6 +481,8 @@ def main():
             "device": info["name"], "arch": info["arch"],
             "parallelism": f"independent herds x{n_gpus}, no collective" + (f"; {per_rank_note}" if per_rank_note else ""),
             "dps_per_step": round(dps / args.steps, 1), "dps_lost": lost,
+            # wave-iterations per launch that left the scheduled loop for the general arithmetic (of lanes/64 * group * 64)
+            "exact_exits_per_step": round(counts.get("exits", 0) / args.steps, 1),
         },
         "roofline": roof,
     }

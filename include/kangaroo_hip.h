@@ -154,7 +154,9 @@ int kng_last_kernel_ms(const kng_engine *h, float *ms);
  *   "dp_ring" 1 (default): the kernel writes its DP records straight into pinned, device-mapped host memory, one buffer
  *            per launch slot, the count landing last; 0 = device buffer + copy at drain time (rounds 1-2)
  *   "steps"  jumps per launch (default KNG_NB_RUN; only tests change it)
- * kng_get_option reads them back (also "lanes", "waves_per_cu"). */
+ * kng_get_option reads them back (also "lanes", "waves_per_cu", and "exact_exits": how many wave-iterations of the last
+ * waited launch the scheduled loop handed to the general arithmetic -- its short forms flag a superset of the operands
+ * they are not exact for). */
 int kng_set_option(kng_engine *h, const char *key, int64_t value);
 int kng_get_option(const kng_engine *h, const char *key, int64_t *value);
 

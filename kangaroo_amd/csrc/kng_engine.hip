@@ -365,6 +365,7 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
                 if (k >= Gs) break;
                 // exact path: some lane of this wave needs the general arithmetic for kangaroo k; nothing of it was stored
                 KNG_RARE_PATH();
+                if (__lane_id() == 0) atomicAdd(a.dp_count + 1, 1u); // how often: kng_get_option("exact_exits")
                 // the statement updates the running product in place: its value before kangaroo k is what kangaroo k - 1 stored
                 fe xi = fe_from32(iv), xa = k ? ld_prod(a.s01, a.s23, slot(k - 1)) : fe_one();
                 const size_t idx = slot(k);
@@ -637,6 +638,7 @@ struct kng_engine {
     int slot_next = 0;        // DP buffer the next launch writes
     int slot_ready = -1;      // DP buffer of the most recently waited launch
     float last_ms = 0.f;
+    uint32_t last_exact_exits = 0; // wave-iterations the scheduled loop handed to the general arithmetic in the last waited launch
     bool lost_warned = false;
     uint64_t bytes = 0;
 };
@@ -874,6 +876,7 @@ int kng_get_option(const kng_engine *h, const char *key, int64_t *value) {
     else if (k == "asm") *value = h->use_asm;
     else if (k == "dp_ring") *value = h->dp_ring;
     else if (k == "dsplit") *value = h->dsplit_on ? 1 : 0;
+    else if (k == "exact_exits") *value = h->last_exact_exits;
     else if (k == "cu_count") *value = h->cu_count;
     else if (k == "waves_per_cu") *value = h->cu_count ? (int64_t)((h->lanes / 64 + h->cu_count - 1) / h->cu_count) : 0;
     else return fail(KNG_E_ARG, "unknown option '%s'", key);
@@ -1050,7 +1053,7 @@ int kng_launch(kng_engine *h) {
     a.n_kang = h->n;
     a.nsteps = h->nsteps;
     a.asm_args = (uint64_t)(h->asm_args + s);
-    HIP_TRY(hipMemsetAsync(h->dp_count[s], 0, 4, h->walk)); // GPUEngine.cu:543
+    HIP_TRY(hipMemsetAsync(h->dp_count[s], 0, 8, h->walk)); // GPUEngine.cu:543 (+ the launch's exact-path exit counter)
     HIP_TRY(hipEventRecord(h->ev_start[s], h->walk));
     const uint32_t blocks = (h->lanes + h->block - 1) / h->block;
     const bool ds = h->dsplit_on;
@@ -1066,7 +1069,7 @@ int kng_launch(kng_engine *h) {
 #undef KNG_LAUNCH
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev_stop[s], h->walk));
-    HIP_TRY(hipMemcpyAsync(h->h_count[s], h->dp_count[s], 4, hipMemcpyDeviceToHost, h->walk));
+    HIP_TRY(hipMemcpyAsync(h->h_count[s], h->dp_count[s], 8, hipMemcpyDeviceToHost, h->walk));
     HIP_TRY(hipEventRecord(h->ev_done[s], h->walk));
     h->outstanding = true;
     return KNG_OK;
@@ -1103,6 +1106,7 @@ int kng_wait(kng_engine *h, int spin) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev_start[s], h->ev_stop[s]));
     h->last_ms = ms;
+    h->last_exact_exits = h->h_count[s][1];
     h->outstanding = false;
     h->slot_ready = s;
     h->slot_next = s ^ 1;
