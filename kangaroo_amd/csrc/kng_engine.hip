@@ -413,7 +413,7 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
 // no barrier).  SHARE = 8: 512-thread blocks, one inversion per CU.  (Round 2 also carried SHARE = 2, SHARE = 3 and two
 // non-template twins of <1,.>: share 3 lost at every herd size, profiles/r02_group_share_sweep.txt; share 2 loses to 8.)
 template <int SHARE, bool DSPLIT, bool ASM>
-__global__ void __launch_bounds__(SHARE == 1 ? 256 : 512) kng_walk_share_kernel(const WalkArgs a) {
+__global__ void __launch_bounds__(SHARE == 1 ? 256 : 512) __attribute__((amdgpu_waves_per_eu(2, 2))) kng_walk_share_kernel(const WalkArgs a) {
     __shared__ uint64_t tab[JT_WORDS];
     __shared__ v16 xch[SHARE == 8 ? 1024 : 1];
     for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
