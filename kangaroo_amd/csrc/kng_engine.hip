@@ -247,7 +247,8 @@ KNG_DEV void walk_core(const WalkArgs &a, const uint64_t *tab, uint64_t *dlo, ui
 //
 // SHARE = 8 (512-thread blocks, option "share", the default): the eight waves of a CU share ONE inversion per jump
 // through a two-level product tree (see the step loop).  Round 1-2's SHARE = 2 (one inversion per SIMD: waves w and
-// w+4) is its first level; sharing the whole CU is +2.5 % on top (profiles/r03_ab_share8.txt) and replaced it.
+// w+4) is its first level; sharing the whole CU was +2.5 % on top and replaced it (every wave for itself against one
+// inversion per CU, both at two waves per SIMD: +5.3 %, profiles/r03_ab_share.txt).
 //     i = 1/(a*b) ;  1/a = i*b ;  1/b = i*a          (3 multiplications per pair and level)
 // Results are unchanged (the canonical residue is the same).
 //
