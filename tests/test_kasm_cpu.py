@@ -196,3 +196,126 @@ def test_valu_flag_mode_is_a_superset_on_the_golden_vectors(golden):
         rcases = [(rnd.getrandbits(256), rnd.getrandbits(256)) for _ in range(128)]
         rgot = _run_binary_op(text, dict(ops, r=[r.phys for r in prod]), rcases)
         assert all(not r and g == kfield.ref_mul(x, y) for (g, r), (x, y) in zip(rgot, rcases))  # random operands: never flagged
+
+
+# ---- the toolkit itself: what the walk loop's correctness on the GPU rests on besides the arithmetic
+
+
+def _tiny(A, schedule=True):
+    """(a, b pinned inputs) -> Asm with one scheduled block"""
+    A.block("A", schedule=schedule)
+
+
+def test_verifier_reports_the_hazards_hipcc_does_not_pad():
+    """gfx940+: a VALU that reads an SGPR written by the VALU instruction right before it needs 2 wait states in between,
+    a VMEM instruction 5; a VALU that overwrites 128-bit store data 2.  Unscheduled text with the violation is reported,
+    the scheduler's output of the same program is clean and contains the pads (nothing else to fill with)."""
+    def build(schedule):
+        A = kasm.Asm()
+        x, y, z = A.v("x", pinned=True), A.v("y", pinned=True), A.v("z", pinned=True)
+        q = A.vt("q", 4, pinned=True)
+        base = A.st("base", 2, pinned=True)
+        c = A.st("c", 2)
+        A.block("A", schedule=schedule)
+        A.v_add_co_u32(x, c, x, y)          # VALU writes the SGPR pair c
+        A.v_addc_co_u32(z, kfield.DUMMY, z, y, c)  # ... and the next VALU reads it: 2 wait states
+        A.global_store(4, x, q, base)
+        A.v_mov_b32(q[0], y)                # overwrites 128-bit store data: 2 wait states
+        A.keep(x, z, q)
+        return A
+
+    raw = build(False)
+    for b in raw.blocks:
+        b.schedule = False
+    # emit exactly as written (no scheduling pass): the verifier must object
+    kasm.allocate(raw, list(range(0, 32)), list(range(0, 32)))
+    probs = kasm.verify(raw)
+    assert any("hazard" in p and "v_addc_co_u32" in p for p in probs), probs
+    assert any("hazard" in p and "v_mov_b32" in p for p in probs), probs
+    fixed = build(True)
+    kasm.schedule(fixed)
+    kasm.allocate(fixed, list(range(0, 32)), list(range(0, 32)))
+    assert kasm.verify(fixed) == []
+    ops = [x.op for x in kasm.linear(fixed) if x.cls not in ("label", "keep")]
+    assert "s_nop" in ops  # nothing independent to put there
+
+
+def test_verifier_reports_a_load_consumed_before_its_wait():
+    A = kasm.Asm()
+    off, base = A.v("off", pinned=True), A.st("base", 2, pinned=True)
+    d, r = A.vt("d", 4), A.v("r", pinned=True)
+    A.block("A", schedule=False)
+    A.global_load(4, d, off, base)
+    A.v_mov_b32(r, d[0])  # no s_waitcnt in between
+    A.keep(r)
+    for b in A.blocks:
+        b.schedule = False
+    kasm.allocate(A, list(range(0, 32)), list(range(0, 32)))
+    probs = kasm.verify(A)
+    assert any("waitcnt" in p for p in probs), probs
+
+
+def test_allocator_aligns_tuples_and_never_overlaps_live_ranges():
+    """64-bit and wider VGPR operands must start on an even register (gfx90a+); two values whose live ranges overlap never
+    share a register; the order is deterministic (the generated header must not depend on object addresses)."""
+    def build():
+        A = kasm.Asm()
+        ins = [A.v(f"i{k}", pinned=True) for k in range(3)]
+        A.block("A")
+        pairs = [A.vt(f"p{k}", 2) for k in range(6)]
+        singles = [A.v(f"s{k}") for k in range(5)]
+        for k, s in enumerate(singles):
+            A.v_add_u32(s, ins[k % 3], ins[(k + 1) % 3])
+        for k, p in enumerate(pairs):
+            A.v_mad_u64_u32(p, kfield.DUMMY, singles[k % 5], ins[k % 3], 0 if k == 0 else pairs[k - 1])
+        A.keep(*pairs[-1].regs, *singles)
+        kasm.schedule(A)
+        used = kasm.allocate(A, list(range(1, 40)), list(range(0, 16)))  # pool starts on an odd register on purpose
+        return A, pairs, singles, used
+
+    A, pairs, singles, used = build()
+    assert all(p.regs[0].phys % 2 == 0 and p.regs[1].phys == p.regs[0].phys + 1 for p in pairs)
+    # live ranges from the final text: a register may be shared only by values that are never live together
+    prog = [x for x in kasm.linear(A) if x.cls not in ("label",)]
+    first, last = {}, {}
+    for pos, x in enumerate(prog):
+        for r in x.defs + x.uses:
+            if r.kind == "v" and not r.pinned:
+                first.setdefault(r, pos)
+                last[r] = pos
+    regs = list(first)
+    for i, a in enumerate(regs):
+        for b in regs[i + 1:]:
+            if a.phys == b.phys:
+                assert last[a] <= first[b] or last[b] <= first[a], (a, b)
+    A2, pairs2, singles2, _ = build()
+    assert [p.regs[0].phys for p in pairs] == [p.regs[0].phys for p in pairs2]
+    assert kasm.listing(A, comments=False) == kasm.listing(A2, comments=False)
+
+
+def test_scheduler_fills_carry_distances_with_independent_work_and_honours_asap():
+    """three independent carry chains: the list scheduler interleaves them instead of padding each link with s_nop; an
+    instruction marked asap issues as soon as its operands exist, whatever the critical path says"""
+    A = kasm.Asm()
+    a = [A.v(f"a{i}", pinned=True) for i in range(6)]
+    b = [A.v(f"b{i}", pinned=True) for i in range(6)]
+    A.block("A")
+    outs = []
+    for chain, (x, y) in enumerate(((a, b), (b, a), (a, a))):
+        c = A.st(f"c{chain}", 2)
+        o = [A.v(f"o{chain}_{i}") for i in range(6)]
+        A.v_add_co_u32(o[0], c, x[0], y[0])
+        for i in range(1, 6):
+            A.v_addc_co_u32(o[i], c, x[i], y[i], c)
+        outs += o
+    t = A.v("t")
+    early = A.v_add_u32(t, a[0], b[0])
+    early.asap = True
+    A.keep(*outs, t)
+    kasm.schedule(A)
+    kasm.allocate(A, list(range(0, 64)), list(range(0, 16)))
+    assert kasm.verify(A) == []
+    prog = [x for x in kasm.linear(A) if x.cls not in ("label", "keep")]
+    st = kasm.stats(A)
+    assert st.get("nop_states", 0) <= 1, st  # a lone chain needs 2 wait states per link (10 per chain); three fill each other's
+    assert prog.index(early) == 0

@@ -398,7 +398,8 @@ SPOOL = list(range(36, 100))
 
 def generate(dsplit, vpool=VPOOL, spool=SPOOL):
     lp = Loop(dsplit).build()
-    kasm.schedule(lp.A)
+    # scheduler pressure limits (live carry masks / live temporaries beyond which only instructions that free registers issue)
+    kasm.schedule(lp.A, sgpr_limit=int(os.environ.get("KASM_SLIM", "28")), vgpr_limit=int(os.environ.get("KASM_VLIM", "150")))
     used = kasm.allocate(lp.A, vpool, spool)
     probs = kasm.verify(lp.A)
     return lp, used, probs
