@@ -162,13 +162,20 @@ def summarise(h):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--kernel", default="kng_walk_share_kernelILi2ELb1")
+    ap.add_argument("--kernel", default="kng_walk_share_kernelILi8ELb1ELb0",
+                    help="mangled-name substring; <SHARE, DSPLIT, ASM> = ILi8ELb1ELb0 is the compiler-scheduled loop of the default geometry")
     ap.add_argument("--src", default=os.path.join(ROOT, "kangaroo_amd", "csrc", "kng_engine.hip"))
     ap.add_argument("--asm", help="use this .s instead of compiling")
     ap.add_argument("--dump", help="write the loop body here")
     ap.add_argument("-D", action="append", default=[])
     ap.add_argument("--top", type=int, default=40)
     a = ap.parse_args()
+    if re.search(r"kng_walk_share_kernelILi\dELb[01]ELb1", a.kernel):
+        # ASM = true: the per-kangaroo loop is ONE generated asm statement (kng_walk_asm.h) that LLVM's loop annotations do not
+        # see -- the loop this tool would find is the compiler-scheduled one of a launch's last step.  The generator prints the
+        # scheduled loop's own instruction mix (tools/gen_walk_asm.py; profiles/r03_isa_stats_after.txt).
+        print("the scheduled asm loop is counted by its generator: python tools/gen_walk_asm.py (see profiles/r03_isa_stats_after.txt)")
+        return
     path = a.asm or compile_s(a.src, a.D)
     body = hot_loop(kernel_lines(path, a.kernel))
     if a.dump:
