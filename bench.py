@@ -213,11 +213,17 @@ def _timed_engine(k, hl, dev, gx, gy, range_power, key_xy, dp, steps, warmup, se
 def secondary_lines(k, hl, dev, gx, gy) -> list:
     """The other kernels and herds BASELINE.json names, next to (never instead of) the headline: kernel-rate only."""
     out = []
-    try:  # configs[3]: 109-bit range, DP 25: jump distances ~2^54 -> both distance words stream (the non-dsplit kernel)
+    try:  # configs[3]: 109-bit range, DP 25: jump distances ~2^54 -- since round 3 still low-word streaming (carries handled in the loop)
         r = _timed_engine(k, hl, dev, gx, gy, 109, _shifted_key(hl, _decompress(P110_PUB), P110_START), 25, 10, 2, 0x110)
-        out.append(dict(r, name="configs[3] puzzle #110: 109-bit range, DP 25, default grid", bytes_per_jump_design=224))
+        out.append(dict(r, name="configs[3] puzzle #110: 109-bit range, DP 25, default grid", bytes_per_jump_design=208 if r["kernel"].split(",")[1].strip() == "true" else 224))
     except Exception as e:
         out.append({"name": "configs[3]", "error": str(e)})
+    try:  # configs[4]'s table: 125-bit range (jump distances ~2^62): both distance words stream (the non-dsplit kernel)
+        _, k125x, k125y = hl.pubkey((1 << 124) + 0xC0FFEE123456789ABCD)
+        r = _timed_engine(k, hl, dev, gx, gy, 125, (k125x, k125y), hl.suggest_dp(125, gx * gy * 128), 10, 2, 0x125)
+        out.append(dict(r, name="configs[4] table: 125-bit range, auto DP, default grid", bytes_per_jump_design=224))
+    except Exception as e:
+        out.append({"name": "configs[4] table", "error": str(e)})
     try:  # configs[2] read literally: herd = 2*CU x 128 kangaroos = grid 2*CU x 1
         _, kx, ky = hl.pubkey(KEY)
         r = _timed_engine(k, hl, dev, gx, 1, RANGE_POWER, _shifted_key(hl, (kx, ky), RANGE_START), hl.suggest_dp(RANGE_POWER, gx * 128), 10, 2, 0x65536)

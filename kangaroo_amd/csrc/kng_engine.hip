@@ -209,8 +209,8 @@ KNG_DEV void walk_core(const WalkArgs &a, const uint64_t *tab, uint64_t *dlo, ui
         if (DSPLIT) {
             if (__builtin_expect(c != 0, 0)) {
                 KNG_RARE_PATH();
-                cd.y = dhi[idx] + 1;
-                dhi[idx] = cd.y;
+                // at L2, like the scheduled loop's carries (global_atomic_add_x2): the two must not meet through a stale L1 line
+                cd.y = atomicAdd(reinterpret_cast<unsigned long long *>(dhi + idx), 1ULL) + 1;
                 hi_known = true;
             }
         } else {
@@ -226,7 +226,7 @@ KNG_DEV void walk_core(const WalkArgs &a, const uint64_t *tab, uint64_t *dlo, ui
     {
         const bool is_dp = (rx.v[3] & a.dp_mask) == 0;
         if (DSPLIT && is_dp && !hi_known) {
-            cd.y = dhi[idx];
+            cd.y = __hip_atomic_load(dhi + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (sees this kernel's L2 atomics)
             // consume the value inside the branch: a load left pending at the join would make hipcc
             // drain every outstanding memory operation (vmcnt(0)) at the top of the next iteration
             asm volatile("" ::"v"(cd.y));
@@ -253,9 +253,11 @@ KNG_DEV void walk_core(const WalkArgs &a, const uint64_t *tab, uint64_t *dlo, ui
 // Results are unchanged (the canonical residue is the same).
 //
 // DSPLIT = true: the 128-bit distance only streams its LOW word through HBM.  d += jD[j] carries out of bit 64
-// with probability jD/2^64 (2^-23 per jump at an 80-bit range); the high word is read-modified-written on
-// that rare path and fetched when a distinguished point is emitted.  Saves 16 of 224 B/jump.  The host
-// enables it when every jump distance is below 2^50 (kng_set_params); results are identical.
+// with probability jD/2^64 (2^-23 per jump at an 80-bit range, 2^-9.5 at 109 bits); the lanes that carry add 1 to their
+// high word with an L2 atomic -- a cold block inside the scheduled loop, nothing waits for it -- and the high word is
+// fetched (coherently) when a distinguished point is emitted.  Saves 16 of 224 B/jump.  The host enables it when every
+// jump distance is below 2^58 (kng_set_params; 2^50 for the compiler-scheduled loop, whose carry path is a divergent
+// read-modify-write): ranges up to 115 bits, BASELINE configs[3] included.  Results are identical.
 //
 // ASM = true (option "asm", the default): the per-kangaroo loop of every step but the last runs as ONE scheduled asm
 // statement (kng_walk_asm.h, generated by tools/gen_walk_asm.py) instead of the compiler-scheduled loop below -- same
@@ -651,7 +653,7 @@ static inline uint64_t *dplane(const kng_engine *h, int hi) { return reinterpret
 // only when a carry out of the low word is rare enough for its read-modify-write not to matter
 static void decide_dsplit(kng_engine *h) {
     const bool possible = h->jd_max != UINT64_MAX;
-    h->dsplit_on = possible && (h->dsplit == 1 || (h->dsplit == -1 && h->jd_max < (1ULL << 50)));
+    h->dsplit_on = possible && (h->dsplit == 1 || (h->dsplit == -1 && h->jd_max < (1ULL << (h->use_asm ? 58 : 50))));
 }
 static DpRecord *dp_buffer(const kng_engine *h, int s) { return h->dp_ring ? h->ring_dev[s] : h->dp_items[s]; }
 // constants of the scheduled loop (WalkAsmArgs), one block per DP buffer; stream-ordered behind any in-flight launch
@@ -860,6 +862,7 @@ int kng_set_option(kng_engine *h, const char *key, int64_t value) {
         if (value < 0 || value > 1) return fail(KNG_E_ARG, "asm must be 0 or 1");
         if (value && (h->n > (1ull << 28) || h->max_found > (1u << 26))) return fail(KNG_E_ARG, "the scheduled loop addresses at most 2^28 kangaroos and 2^26 DP records");
         h->use_asm = (int)value;
+        decide_dsplit(h); // (the automatic choice depends on which loop runs)
     } else {
         return fail(KNG_E_ARG, "unknown option '%s'", key);
     }

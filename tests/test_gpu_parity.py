@@ -332,12 +332,14 @@ def test_full_size_herd_properties(kng, orc):
 
 @pytest.mark.parametrize("use_asm", [1, 0])
 @pytest.mark.parametrize("share", [1, 8])
-@pytest.mark.parametrize("rp,dsplit", [(72, 1), (109, 0)])
-def test_every_walk_kernel_vs_oracle(kng, orc, share, rp, dsplit, use_asm):
+@pytest.mark.parametrize("rp", [72, 109, 125])
+def test_every_walk_kernel_vs_oracle(kng, orc, share, rp, use_asm):
     """All eight instantiations of the walk kernel -- share 1/8 x {low-word distance streaming, both words} x {scheduled
-    asm loop, compiler-scheduled loop} -- as the engine itself selects them: a 72-bit range streams only the low word,
-    BASELINE configs[3]'s 109-bit range (jump distances around 2^54) streams both.  States and the exact DP multiset
-    over two launches."""
+    asm loop, compiler-scheduled loop} -- as the engine itself selects them: a 72-bit range streams only the low word;
+    BASELINE configs[3]'s 109-bit range (jump distances around 2^54: a lane's low word carries every ~700 jumps) still
+    does with the scheduled loop, which adds the carries in the loop with L2 atomics, and streams both words with the
+    compiler loop; configs[4]'s 125-bit range streams both.  States and the exact DP multiset over two launches."""
+    dsplit = {72: 1, 109: 1 if use_asm else 0, 125: 0}[rp]
     grid = (4, 4)
     n = grid[0] * grid[1] * 128
     x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=1000 + rp + share)
@@ -406,12 +408,14 @@ def test_dp_ring_delivers_the_same_records(kng, orc, use_asm, ring):
     small.close()
 
 
-@pytest.mark.parametrize("rp,dp,dsplit", [(80, 14, 1), (80, 14, 0), (109, 25, 0)])
+@pytest.mark.parametrize("rp,dp,dsplit", [(80, 14, 1), (80, 14, 0), (109, 25, 1), (109, 25, 0)])
 def test_bench_config_total_parity(kng, orc, rp, dp, dsplit):
     """BASELINE.md 3's gate taken literally, at the bench configuration (80-bit range, grid 512x128 = 2^23 kangaroos,
     auto DP 14, default kernel): after one launch ALL 2^23 (x, y, d) triples and the COMPLETE distinguished-point
     multiset equal the oracle's (walked over a thread pool: kangaroos are independent).  Both distance layouts, and the
-    puzzle-#110 table (BASELINE configs[3]: 109-bit range, DP 25, jump distances ~2^54) at the same herd."""
+    puzzle-#110 table (BASELINE configs[3]: 109-bit range, DP 25, jump distances ~2^54) at the same herd -- in the layout
+    the engine picks for it since round 3 (low word streams, ~12 000 carries per jump of the herd go through L2 atomics) and
+    with both words streaming."""
     import kangaroo_amd.hostlib as hl
 
     gx, gy = 512, 128
@@ -770,7 +774,7 @@ def test_exact_path_exits_of_the_scheduled_loop(kng, orc, share, dsplit):
     jd, jx, jy, _ = orc.jump_table(rp)
     if not dsplit:
         jd = jd.copy()
-        jd[:, 0] |= np.uint64(1 << 55)  # distances the engine will not stream low-word-only
+        jd[:, 0] |= np.uint64(1 << 60)  # distances the engine will not stream low-word-only (>= 2^58)
     rng = np.random.default_rng(5)
     d = np.zeros((n, 2), np.uint64)  # raw device distances (no wild offset set: Set/Get pass them through)
     d[:, 0] = rng.integers(0, (1 << 63), size=n, dtype=np.uint64)
@@ -818,10 +822,15 @@ def test_exact_path_exits_of_the_scheduled_loop(kng, orc, share, dsplit):
 
 def test_distance_low_word_streaming_is_chosen_by_the_jump_table(kng, orc):
     eng = kng.GPUEngine(2, 2, 0, 1 << 12)
-    for rp, want in ((72, 1), (98, 1), (100, 0), (125, 0)):  # jump distances < 2^(rp/2+1): auto below 2^50
-        jd, jx, jy, _ = orc.jump_table(rp)
-        eng.SetParams(orc.dp_mask(8), jd, jx, jy)
-        assert eng.get_option("dsplit") == want, rp
+    # jump distances < 2^(rp/2+1).  Scheduled loop (carries added in the loop by L2 atomics): automatic below 2^58, i.e. up to
+    # 115-bit ranges; compiler-scheduled loop (divergent read-modify-write): below 2^50
+    for use_asm, cases in ((1, ((72, 1), (98, 1), (100, 1), (109, 1), (115, 1), (116, 0), (125, 0))), (0, ((72, 1), (98, 1), (100, 0), (125, 0)))):
+        eng.set_option("asm", use_asm)
+        for rp, want in cases:
+            jd, jx, jy, _ = orc.jump_table(rp)
+            eng.SetParams(orc.dp_mask(8), jd, jx, jy)
+            assert eng.get_option("dsplit") == want, (use_asm, rp)
+    eng.set_option("asm", 1)
     jd, jx, jy, _ = orc.jump_table(72)
     jd = jd.copy()
     jd[5, 1] = 1  # a high word in the table: never, even when forced

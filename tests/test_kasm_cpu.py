@@ -117,14 +117,14 @@ def test_walk_loop_verifies_clean(dsplit):
     dict(L=8, G=5, steps=2, dsplit=False, jd_bits=100),
     dict(L=8, G=1, steps=2, dsplit=True),
     dict(L=8, G=2, steps=3, dsplit=False, jd_bits=90),
-    dict(L=8, G=4, steps=2, dsplit=True, jd_bits=64, seed=3),   # low-word carries: exact-path exits nearly every iteration
+    dict(L=8, G=4, steps=2, dsplit=True, jd_bits=64, seed=3),   # low-word carries in most iterations: added to the high words by L2 atomics, in the loop
     dict(L=64, G=3, steps=2, dsplit=True, dp_bits=2, jd_bits=40, seed=5),  # full wave, several DPs per wave-iteration
     dict(L=64, G=2, steps=2, dsplit=False, dp_bits=1, jd_bits=70, seed=6),
 ])
 def test_walk_loop_against_integer_model(case):
     stats = kwalk_emu.run_case(verbose=False, **case)
     if case.get("jd_bits") == 64:
-        assert stats.get("rare_exits", 0) > 0
+        assert stats.get("rare_exits", 0) == 0  # (rounds 1-3a left the loop for every carry; the states above include the high words)
 
 
 def test_walk_loop_dp_overflow_is_counted_not_stored():

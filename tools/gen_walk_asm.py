@@ -92,6 +92,10 @@ class Loop:
         # cache-hint experiments (default: x, y stream with nt; products and distances plain): letters of KASM_NT flip one each
         #   S product loads nt   s product stores nt   d distance loads + stores nt   X x/y loads plain   x x/y stores plain
         self.nt = os.environ.get("KASM_NT", "")
+        # low-word distance streaming: a carry out of the low word either leaves the loop for the exact path ("exit": rounds 1-3a,
+        # only sensible when carries are ~2^-23 per jump) or is added to the high word by an L2 atomic without leaving ("atomic":
+        # one cold block per carrying wave-iteration, which makes the layout pay for jump distances up to 2^58)
+        self.carry_mode = os.environ.get("KASM_CARRY", "atomic")
         if "noflags" in self.abl:
             A.s_or_accum = lambda acc, m: None
 
@@ -264,7 +268,8 @@ class Loop:
         A.v_add_co_u32(DN[0], dc, cd[0], JD[0])
         A.v_addc_co_u32(DN[1], dc, cd[1], JD[1], dc)
         if self.dsplit:
-            A.s_or_accum(self.rare, dc)  # carry out of the low word: the high word is updated on the exact path
+            if self.carry_mode != "atomic":
+                A.s_or_accum(self.rare, dc)  # carry out of the low word: the high word is updated on the exact path
         else:
             A.v_addc_co_u32(DN[2], dc, cd[2], JD[2], dc)
             A.v_addc_co_u32(DN[3], "vcc", cd[3], JD[3], dc)
@@ -292,7 +297,7 @@ class Loop:
         if F.flag_mode == "valu":
             F.end_flags(T("fl"))
         # everything the stores and the commit need must be complete here
-        A.keep(*INVn, *RX, *RY, *ACCn, *DN.regs[:2 if self.dsplit else 4], DPM)
+        A.keep(*INVn, *RX, *RY, *ACCn, *DN.regs[:2 if self.dsplit else 4], DPM, *([dc] if self.dsplit and self.carry_mode == "atomic" else []))
         A.s_cmp("lg_u64", self.rare, 0)
         A.s_cbranch_scc1(L_rare)
         # ---------------- block B: stores, DP records, commit
@@ -314,6 +319,22 @@ class Loop:
             A.global_store(4, voff, ACCq[0], self.P["s01"], nt="s" in self.nt)
             A.global_store(4, voff, ACCq[1], self.P["s23"], nt="s" in self.nt)
             n_after += 2
+        if self.dsplit and self.carry_mode == "atomic":
+            # ---- cold: lanes whose low word carried add 1 to their high word, at L2, without waiting for anything
+            L_nc = f".Lkw_nocarry{tag}_%="
+            A.s_cmp("lg_u64", dc, 0)
+            A.s_cbranch_scc0(L_nc)
+            A.cur.schedule = False
+            A.raw("; cold path")
+            SAVEC, ONEC = A.st(T("savec"), 2), A.vt(T("onec"), 2)
+            A.s_mov_b64(SAVEC, EXEC)
+            A.v_mov_b32(ONEC[0], 1)
+            A.v_mov_b32(ONEC[1], 0)
+            A.s_mov_exec(dc)
+            A.global_atomic_add_x2(voff8, ONEC, self.P["dhi"])
+            A.s_mov_exec(SAVEC)
+            A.label(L_nc)
+            A.cur.schedule = False
         A.s_cmp("lg_u64", DPM, 0)
         A.s_cbranch_scc0(L_nodp)
         # ---- cold: wave-compacted DP records (emit_dp of kng_engine.hip; GPUCompute.h:96-105)
@@ -326,7 +347,7 @@ class Loop:
         A.s_mov_b64(SAVE, EXEC)
         if self.dsplit:
             A.s_mov_exec(DPM)
-            A.global_load(2, DN.sub(2, 2), voff8, self.P["dhi"])
+            A.global_load(2, DN.sub(2, 2), voff8, self.P["dhi"], coherent=self.carry_mode == "atomic")  # (sees this kernel's L2 atomics)
             A.s_mov_exec(SAVE)
         A.s_bcnt1_i32_b64(scnt, DPM)
         A.v_mbcnt_lo(vpos, DPM[0], 0)

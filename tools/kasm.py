@@ -396,10 +396,11 @@ class Asm:
     def _mem(self, op, args, defs, uses, cls, mods):
         return self.emit(Ins(op, args, defs=list(defs) + [MEMTOK], uses=list(uses) + [MEMTOK, EXEC], cls=cls, mods=mods))
 
-    def global_load(self, width, d, voff, sbase, offset=0, nt=False):
-        """d <- [sbase + zext(voff) + offset]; width in dwords (1, 2, 4)"""
+    def global_load(self, width, d, voff, sbase, offset=0, nt=False, coherent=False):
+        """d <- [sbase + zext(voff) + offset]; width in dwords (1, 2, 4).  coherent: sc0 sc1 (served by L2, never by a line the
+        vector L1 still holds: what a load must carry to see an L2 atomic of the same kernel)"""
         op = {1: "global_load_dword", 2: "global_load_dwordx2", 4: "global_load_dwordx4"}[width]
-        mods = (f"offset:{offset}" if offset else "") + (" nt" if nt else "")
+        mods = (f"offset:{offset}" if offset else "") + (" nt" if nt else "") + (" sc0 sc1" if coherent else "")
         return self._mem(op, [d, voff, sbase], [d], [voff, sbase], "vmem_ld", mods.strip())
 
     def global_store(self, width, voff, data, sbase, offset=0, nt=False):
@@ -409,6 +410,10 @@ class Asm:
 
     def global_atomic_add_rtn(self, d, voff, data, sbase):
         return self._mem("global_atomic_add", [d, voff, data, sbase], [d], [voff, data, sbase], "vmem_ld", "sc0")
+
+    def global_atomic_add_x2(self, voff, data, sbase):
+        """[sbase + zext(voff)] += data (64 bit), no return value: counted in vmcnt like a store"""
+        return self._mem("global_atomic_add_x2", [voff, data, sbase], [], [voff, data, sbase], "vmem_st", "")
 
     def ds_read_b64(self, d, addr, offset=0):
         return self._mem("ds_read_b64", [d, addr], [d], [addr], "lds", f"offset:{offset}" if offset else "")

@@ -549,6 +549,17 @@ class Emu:
             self.mem.write(addr, struct.pack("<I", (old + self.vsrc32(a[2], l)) & M32))
             self.v[d][l] = old
 
+    def op_global_atomic_add_x2(self, a, m, f):
+        # non-returning form: voff, vdata(64), saddr
+        assert "sc0" not in f
+        regs = self.vrange(a[1])
+        assert len(regs) == 2
+        for l in self.lanes():
+            addr = self._gaddr(a[0], a[2], m, l)
+            old = struct.unpack("<Q", self.mem.read(addr, 8))[0]
+            add = self.v[regs[0]][l] | (self.v[regs[1]][l] << 32)
+            self.mem.write(addr, struct.pack("<Q", (old + add) & ((1 << 64) - 1)))
+
     def op_ds_read_b64(self, a, m, f):
         regs = self.vrange(a[0])
         assert len(regs) == 2
