@@ -147,7 +147,8 @@ int kng_last_kernel_ms(const kng_engine *h, float *ms);
  *   "share"  waves that share one modular inversion per jump: 1 = none (256-thread blocks), 8 (default) = the eight
  *            waves of a 512-thread block, i.e. one inversion per CU ("block" is then ignored)
  *   "dsplit" -1 (default): stream only the low word of the 128-bit distances through HBM when every jump
- *            distance given to kng_set_params is below 2^50 (the high word is then updated on the rare carry);
+ *            distance given to kng_set_params is below 2^58 (ranges up to 115 bits; 2^50 with "asm" 0): the high word
+ *            is then updated by an L2 atomic of the lanes whose low word carried;
  *            0 = never, 1 = whenever the table allows it (all high words zero).  Reads back 0/1 = in effect.
  *   "asm"    1 (default): the per-kangaroo loop runs as one scheduled asm statement (kng_walk_asm.h); 0 = the
  *            compiler-scheduled loop (also what herds beyond 2^28 kangaroos get).  Same results.
