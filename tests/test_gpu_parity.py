@@ -820,6 +820,46 @@ def test_exact_path_exits_of_the_scheduled_loop(kng, orc, share, dsplit):
     eng.close()
 
 
+def test_low_word_carries_accumulate_over_many_launches_at_109_bits(kng, orc):
+    """BASELINE configs[3]'s table (109-bit range, jump distances ~2^54) on the default kernel: the low word of a lane's
+    distance carries every ~700 jumps, and each carry is an L2 atomic on the high word from inside the scheduled loop.  50
+    launches = 3200 jumps of 131 072 kangaroos (~4.5 carries per kangaroo, ~600 000 atomics, DP records in between fetch the
+    high words coherently): every (x, y, d) and the complete DP multiset equal the oracle's walk of the same herd."""
+    import kangaroo_amd.hostlib as hl
+
+    rp, gx, gy, dp, launches = 109, 8, 128, 12, 50
+    n = gx * gy * 128
+    _, kx, ky = hl.pubkey((1 << 108) + 0xC0FFEE123456789ABCD)
+    jd, jx, jy, _ = hl.jump_table(rp)
+    mask = hl.dp_mask(dp)
+    got = []
+    with kng.GPUEngine(gx, gy, 0, 1 << 17) as eng:
+        eng.SetParams(mask, jd, jx, jy)
+        assert eng.get_option("dsplit") == 1 and eng.get_option("asm") == 1 and eng.get_option("share") == 8
+        eng.CreateHerdOnDevice(rp, (kx, ky), seed=0x109)
+        x0, y0, d0 = eng.GetKangaroos(raw=True)
+        for _ in range(launches):
+            eng.callKernel()
+            eng.wait()
+            got.append(eng.drain(raw=True))
+            assert eng.lastLost == 0
+        x1, y1, d1 = eng.GetKangaroos(raw=True)
+    got = np.concatenate(got)
+    hi_before = d0[:, 1].copy()
+    want = orc.walk_parallel(x0, y0, d0, 64 * launches, jd, jx, jy, mask)
+    assert np.array_equal(x1, x0) and np.array_equal(y1, y0) and np.array_equal(d1, d0)  # x0.. now hold the oracle's end state
+    carries = int((d0[:, 1] - hi_before).sum())
+    assert 2.5 * n < carries < 7 * n, carries  # jD ~ 2^54 of 2^64 per jump, 3200 jumps
+    assert len(got) == len(want)
+
+    def canon(r):
+        o = np.lexsort((r["d"][:, 1], r["d"][:, 0], r["kidx"]))
+        return r["kidx"][o], r["x"][o], r["d"][o]
+
+    for a, b in zip(canon(got), canon(want)):
+        assert np.array_equal(a, b)
+
+
 def test_distance_low_word_streaming_is_chosen_by_the_jump_table(kng, orc):
     eng = kng.GPUEngine(2, 2, 0, 1 << 12)
     # jump distances < 2^(rp/2+1).  Scheduled loop (carries added in the loop by L2 atomics): automatic below 2^58, i.e. up to
