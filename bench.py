@@ -137,6 +137,37 @@ def _roofline(kernel, kms, n, nb_run, group, note=None, sustained_ms=None):
     return r
 
 
+# ---- second bound: the package power cap.  Inputs measured on this chip in earlier rounds:
+#   profiles/r01_instr_energy.txt   342 W with nothing but s_nop on every SIMD (static + clocks); per wave64 instruction
+#                                   v_mad_u64_u32 1.38 nJ, carry / VOP3 ops 0.75 nJ, moves 0.36 nJ
+#   profiles/r02_memory_energy.txt  ~100 pJ per byte moved through L2 / fabric / HBM (copy 102, read 93, write 115)
+#   tools/gen_walk_asm.py           static count of the scheduled loop per kangaroo-jump: 410 MAD, 475 other slow, 140 fast VALU
+P_STATIC_W = 342.0
+E_VALU_NJ_PER_WAVE_JUMP = 410 * 1.38 + 475 * 0.75 + 140 * 0.36
+E_MEM_NJ_PER_BYTE = 0.100
+DESIGN_BYTES_PER_JUMP = 208.0
+
+
+def _power_bound(power_summary, bytes_per_jump, rate_mks):
+    """roofline.power_bound: the jump rate at which the kernel's dynamic energy per jump uses up (P_cap - P_static)."""
+    dev = (power_summary.get("devices") or [{}])[0] if power_summary.get("available") else {}
+    cap = dev.get("power_cap_w")
+    e_dyn = E_VALU_NJ_PER_WAVE_JUMP / 64.0 + bytes_per_jump * E_MEM_NJ_PER_BYTE  # nJ per kangaroo-jump
+    out = {"formula": "(P_cap - P_static) / E_dyn_per_jump", "p_static_w": P_STATIC_W, "e_dyn_nj_per_jump": round(e_dyn, 2),
+           "e_valu_nj_per_jump": round(E_VALU_NJ_PER_WAVE_JUMP / 64.0, 2), "e_mem_nj_per_jump": round(bytes_per_jump * E_MEM_NJ_PER_BYTE, 2),
+           "bytes_per_jump": bytes_per_jump, "p_cap_w": cap,
+           "inputs": "profiles/r01_instr_energy.txt, profiles/r02_memory_energy.txt, static instruction count of tools/gen_walk_asm.py"}
+    if cap:
+        out["value_mks"] = round((cap - P_STATIC_W) / (e_dyn * 1e-9) / 1e6, 0)
+    pw = (dev.get("power_w") or {}).get("median") or dev.get("power_w_from_energy_counter")
+    if pw and rate_mks:
+        out["measured_power_w"] = pw
+        out["measured_nj_per_jump"] = round(pw / (rate_mks * 1e6) * 1e9, 2)             # everything, static included
+        out["value_at_measured_power_mks"] = round((pw - P_STATIC_W) / (e_dyn * 1e-9) / 1e6, 0)
+        out["frac_of_bound_at_measured_power"] = round(rate_mks / out["value_at_measured_power_mks"], 3)
+    return out
+
+
 def _decompress(pub_hex):
     P = 2**256 - 0x1000003D1
     x = int(pub_hex[2:], 16)
@@ -279,6 +310,11 @@ def bench_multi(args, ranks, n_gpus):
             s.close()
         ranks.abort()
         raise SystemExit(1)  # EVERY rank leaves non-zero, promptly
+    sampler = None
+    if ranks.rank == 0:
+        from kangaroo_amd.telemetry import GpuSampler
+
+        sampler = GpuSampler(sorted(set(devices)), hz=20.0).start()
     try:
         elapsed = timed_on_rank0(ranks, job.get("run"))
     except RankFailure as e:
@@ -286,6 +322,7 @@ def bench_multi(args, ranks, n_gpus):
         ranks.abort()
         raise SystemExit(1)
     if ranks.rank == 0:
+        power = sampler.stop().summary()
         st = s.stats()
         per_gpu = []
         for g in range(n_gpus):
@@ -317,6 +354,7 @@ def bench_multi(args, ranks, n_gpus):
                 "what_is_timed": "kngs_start .. every GPU finished its K launches AND every distinguished point is in the table",
             },
             "per_gpu": per_gpu,
+            "power": {"timed_region": power},  # per device: package power, GFX clock (rocm_smi index = HIP index assumed)
             "kernel_rate_sum": round(sum(p["kernel_rate"] for p in per_gpu), 1),
             "roofline": _roofline(kernel, kms, n, k.KNG_NB_RUN, group, note="per GPU, mean over GPUs"),
         }
@@ -459,7 +497,11 @@ def main():
         counts["dps"] += len(eng.drain(raw=True))
         counts["lost"] += eng.lastLost
 
+    from kangaroo_amd.telemetry import GpuSampler
+
+    sampler = GpuSampler([dev], hz=50.0).start()  # package power / GFX clock across the timed region (a thread, off the data path)
     elapsed = timed_steps(ranks, step, finish, args.steps)  # barrier+sync, K steps, barrier+sync, max over ranks
+    power = sampler.stop().summary()
     dps, lost = counts["dps"], counts["lost"]
 
     jumps_per_step = n * k.KNG_NB_RUN
@@ -491,7 +533,12 @@ def main():
             "exact_exits_per_step": round(counts.get("exits", 0) / args.steps, 1),
         },
         "roofline": roof,
+        # the limiter, in the line itself: package power and GFX clock over the timed region (50 Hz samples + the device's
+        # energy accumulator); `sustained` below repeats it over the pipeline leg's longer run
+        "power": {"timed_region": power},
     }
+    bpj = (roof["traffic"] / (n * k.KNG_NB_RUN)) if roof.get("traffic") else DESIGN_BYTES_PER_JUMP
+    roof["power_bound"] = _power_bound(power, round(bpj, 1), n * k.KNG_NB_RUN / (kms * 1e-3) / 1e6)
     eng.close()
     if rank == 0 and n_gpus == 1 and not args.no_secondary:
         out["secondary"] = secondary_lines(k, hl, dev, gx, gy)
@@ -502,17 +549,27 @@ def main():
             from kangaroo_amd import solver as sv
 
             s = sv.Solver(RANGE_START, RANGE_START + (1 << RANGE_POWER) - 1, (kx, ky), gpus=(local_rank,), grid=(gx, gy), dp=dp,
-                          seed=0x5EED, max_launches=max(10, args.steps))
+                          seed=0x5EED, max_launches=max(100, args.steps))  # ~2 s: long enough for the clock governor to settle
+            s.prepare()
+            sampler = GpuSampler([dev], hz=50.0).start()
             s.start()
             s.wait(120)
+            sustained = sampler.stop().summary()
             st = s.stats()
+            # whole-run audit on the device: every kangaroo and every table entry re-derived from its distance (kngs_audit)
+            aud = s.audit(True)
             s.stop()
             s.close()
+            out["power"]["sustained"] = sustained
             # the sustained figure next to the 0.5-second headline: the same kernel over the pipeline's longer run
             roof["frac_sustained"] = round(jumps_per_step * ALG_BYTES_PER_JUMP / (st["kernel_ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             roof["sustained_kernel_ms"] = round(st["kernel_ms_avg"], 3)
             out["pipeline"] = {"value": round(st["jumps"] / st["seconds"] / 1e6, 2), "unit": "MK/s", "launches": st["launches"],
                                "kernel_ms_avg": round(st["kernel_ms_avg"], 3), "dps": st["dps"], "dps_lost": st["dps_lost"],
+                               "audited_kangaroos": aud["kangaroos"], "audit_mismatches": aud["kangaroo_mismatches"] + aud["table_mismatches"],
+                               "audited_table_points": aud["table_points"], "audit_ms": round(aud["herd_ms"] + aud["table_ms"], 2),
+                               "audit": "every kangaroo (x, y) and every table entry re-derived from its distance on the device after the run",
+                               "jumps_audited_log2": round(float(np.log2(max(1, st["jumps"]))), 2),
                                "what": "kngs_* solver: async DP drain + sharded DP table, wall clock incl. first and last launch"}
         except Exception as e:
             out["pipeline"] = {"value": None, "unit": "MK/s", "what": f"failed: {e}"}

@@ -58,6 +58,9 @@ int kng_device_count(void);
 /* name (<= name_cap bytes incl. NUL), compute units, total memory, gcn arch string */
 int kng_device_info(int dev, char *name, size_t name_cap, int *cu_count, uint64_t *mem_bytes,
                     char *arch, size_t arch_cap);
+/* free / total device memory right now (hipMemGetInfo): lets a host that re-creates its engine once per key
+ * (Kangaroo.cpp:1021-1075, ctor :523, `delete gpu` :634) check that a create / destroy cycle gives everything back */
+int kng_device_free_bytes(int dev, uint64_t *free_bytes, uint64_t *total_bytes);
 /* fills *x / *y when <= 0 with the reference's defaults: x = 2*CU count, y = 128
  * (GPUEngine.cu:299-303; the per-SM core table has no AMD entry, so y falls back to 128) */
 int kng_default_grid(int dev, int *x, int *y);
@@ -71,7 +74,9 @@ uint64_t kng_nb_kangaroos(const kng_engine *h); /* GetNbThread()*GetGroupSize(),
 uint64_t kng_memory_bytes(const kng_engine *h); /* GetMemory(), GPUEngine.cu:266-268 (64-bit)  */
 
 /* ---- parameters: SetParams, GPUEngine.cu:559-590 ---------------------------------------------- */
-/* jd: [32][2], jx/jy: [32][4] limbs */
+/* jd: [32][2], jx/jy: [32][4] limbs.  May be called while a launch is outstanding: the uploads are ordered on the walk
+ * stream, so that launch finishes with the table and mask it started with, the call blocks until it has (like the
+ * reference's cudaMemcpyToSymbol, :565-583), and the next launch uses the new parameters. */
 int kng_set_params(kng_engine *h, uint64_t dp_mask, const uint64_t *jd, const uint64_t *jx,
                    const uint64_t *jy);
 
@@ -125,8 +130,12 @@ int kng_wait(kng_engine *h, int spin);
 int kng_drain(kng_engine *h, kng_item *items, uint32_t cap, uint32_t *n_items, uint32_t *n_lost);
 /* the same without the per-item copy: *records points at the engine's pinned landing buffer (64-byte records, the
  * layout the kernel writes: OutputDP of GPUMath.h:173-188 padded to four 16-byte stores) holding *n_items points.
- * The view stays valid until the next kng_drain / kng_drain_view of this engine.  For hosts that ingest ~10^5
- * points per launch (many GPUs share a small DP size, Kangaroo.cpp:980-993). */
+ * For hosts that ingest ~10^5 points per launch (many GPUs share a small DP size, Kangaroo.cpp:980-993).
+ * LIFETIME of the view: until the next kng_drain / kng_drain_view of this engine, and -- with "dp_ring" 1, where the
+ * view IS the buffer the kernel wrote -- at most until the SECOND kng_launch after the kng_wait that completed its launch:
+ * the two landing buffers alternate, so in the pipelined order  wait A, launch B, drain_view A, wait B, launch C  the
+ * kernel of launch C writes the buffer view A points into.  Consume (or copy) a view before waiting for the next launch;
+ * kng_drain copies and has no such limit. */
 typedef struct kng_dp_record {
     uint64_t x[4];
     uint64_t d[2]; /* device distance: wild kangaroos (odd kidx) still carry +wildOffset */
@@ -134,6 +143,29 @@ typedef struct kng_dp_record {
     uint64_t reserved;
 } kng_dp_record;
 int kng_drain_view(kng_engine *h, const kng_dp_record **records, uint32_t *n_items, uint32_t *n_lost);
+
+/* ---- whole-run audit on the device (new; the reference's closest tools are -wcheck, Check.cpp:141-411, which re-derives
+ *      every stored distinguished point from its distance on the CPU, and the final key check, Kangaroo.cpp:196-206) ----
+ * A walk error is permanent for its kangaroo: the invariant  (x, y) = d*G (tame) / K + d*G (wild)  holds after every exact
+ * jump and never again after an inexact one.  The audit recomputes that point from the 128-bit DEVICE distance dd alone,
+ *     base_type + dd*G + final_add     (type = kidx & 1; inputs as for kng_build_herd, with the full 16 windows:
+ *                                       kngh_herd_params(128, ...) of the host library),
+ * with general arithmetic only (nothing of the scheduled loop's short forms), and compares it with what the walk left.
+ * kng_audit_setup uploads the inputs once (table: [16][256][8] limbs).
+ * kng_audit_herd checks every kangaroo of the herd in x AND y; no launch may be outstanding (it borrows the walk's
+ *   product planes; 4 x 16 B x herd of scratch are allocated for the call).
+ * kng_audit_points checks n 64-byte records {x, d, kidx, reserved}: reserved = 0 compares all 256 bits of x (what
+ *   kng_drain_view returns), reserved = 1 only what a hash-table entry keeps of x (limbs 0-1 and the 18 bucket bits of
+ *   limb 2, HashTable.h:27-56).  Runs on its own stream: allowed while a launch is outstanding.
+ * *n_bad = number of mismatches; the first min(bad_cap, 1024 per 2^21 records) offending indices (kIdx resp. position in
+ * `recs`) go to bad_idx (may be NULL).  A zero distance has no affine point and counts as a mismatch.
+ * kng_get_option "audit_us" = kernel time of the last audit call. */
+#define KNG_AUDIT_WINDOWS 16
+int kng_audit_setup(kng_engine *h, const uint64_t *table, const uint64_t base_tame[8], const uint64_t base_wild[8],
+                    const uint64_t final_add[8]);
+int kng_audit_herd(kng_engine *h, uint64_t *n_bad, uint64_t *bad_idx, uint32_t bad_cap);
+int kng_audit_points(kng_engine *h, const kng_dp_record *recs, uint64_t n, uint64_t *n_bad, uint64_t *bad_idx,
+                     uint32_t bad_cap);
 
 /* ---- measurement (new; the reference only has the host-side MK/s average, Thread.cpp:254-300) */
 /* HIP-event duration (ms) of the walk kernel of the most recently waited launch, measured on
@@ -144,8 +176,8 @@ int kng_last_kernel_ms(const kng_engine *h, float *ms);
  *   "lanes"  alternatively the lane count itself (multiple of 64, need not divide the herd: waves then
  *            walk ceil or floor of herd/lanes kangaroos)
  *   "block"  threads per workgroup (multiple of 64)
- *   "share"  waves that share one modular inversion per jump: 1 = none (256-thread blocks), 8 (default) = the eight
- *            waves of a 512-thread block, i.e. one inversion per CU ("block" is then ignored)
+ *   "share"  waves that share one modular inversion per jump: 8 = the eight waves of a 512-thread block, i.e. one
+ *            inversion per CU -- the only form left (rounds 1-3 also carried 1 = every wave inverts for itself)
  *   "dsplit" -1 (default): stream only the low word of the 128-bit distances through HBM when every jump
  *            distance given to kng_set_params is below 2^58 (ranges up to 115 bits; 2^50 with "asm" 0): the high word
  *            is then updated by an L2 atomic of the lanes whose low word carried;
@@ -153,7 +185,9 @@ int kng_last_kernel_ms(const kng_engine *h, float *ms);
  *   "asm"    1 (default): the per-kangaroo loop runs as one scheduled asm statement (kng_walk_asm.h); 0 = the
  *            compiler-scheduled loop (also what herds beyond 2^28 kangaroos get).  Same results.
  *   "dp_ring" 1 (default): the kernel writes its DP records straight into pinned, device-mapped host memory, one buffer
- *            per launch slot, the count landing last; 0 = device buffer + copy at drain time (rounds 1-2)
+ *            per launch slot, the count landing last; 0 = device buffer + copy at drain time (rounds 1-2).  Only the
+ *            buffers of the mode in use are allocated; switching releases the others and fails with KNG_E_STATE while
+ *            a waited launch has not been drained
  *   "steps"  jumps per launch (default KNG_NB_RUN; only tests change it)
  * kng_get_option reads them back (also "lanes", "waves_per_cu", and "exact_exits": how many wave-iterations of the last
  * waited launch the scheduled loop handed to the general arithmetic -- its short forms flag a superset of the operands

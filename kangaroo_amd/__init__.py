@@ -7,7 +7,7 @@ the C ABI with ctypes for the test-suite and bench.py.  There is no CPU fallback
 anywhere, creating an engine needs a gfx950 device.
 """
 from .engine import (KNG_GRP_SIZE, KNG_NB_JUMP, KNG_NB_RUN, EngineError, GPUEngine, device_count,  # noqa: F401
-                     device_info, default_grid, load_library, test_fieldop)
+                     device_info, device_free_bytes, default_grid, load_library, test_fieldop)
 
-__all__ = ["GPUEngine", "EngineError", "device_count", "device_info", "default_grid", "load_library",
+__all__ = ["GPUEngine", "EngineError", "device_count", "device_info", "device_free_bytes", "default_grid", "load_library",
            "test_fieldop", "KNG_NB_JUMP", "KNG_NB_RUN", "KNG_GRP_SIZE"]

@@ -539,6 +539,120 @@ __global__ void __launch_bounds__(256) kng_herd_kernel(const HerdArgs a) {
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// whole-run audit on the device (new; the device-side counterpart of the reference's -wcheck, Check.cpp:141-411, which
+// re-derives every stored distinguished point from its distance, and of Kangaroo::Output's final check, Kangaroo.cpp:196-206).
+// A walk error is permanent for its kangaroo: (x, y) = d*G (tame) / K + d*G (wild) holds after every exact jump and never
+// again after an inexact one.  The audit recomputes that point from the 128-bit device distance alone -- with the herd
+// builder's machinery (16 windows of 8 bits + the closing constant, one batched inversion per lane and window; general
+// arithmetic only, nothing of the scheduled loop's short forms) -- and compares it with what the walk left:
+//   HERD mode  every kangaroo of the engine's herd, x AND y (256 bits each, canonical residues compared);
+//   RECS mode  an array of 64-byte DP records {x, d, kidx, mode}: mode 0 compares all of x, mode 1 only what a hash-table
+//              entry keeps of it (limbs 0-1 and the 18 bucket bits of limb 2, HashTable.h:27-56).
+// A distance of zero has no affine point (the offset form would add b*G and -b*G): it is reported as a mismatch without
+// entering the lane's product chain.
+struct AuditArgs {
+    HerdArgs h;                            // x01..y23, s01, s23 = SCRATCH planes of h.n_kang vectors; table / base / fin / windows / lanes as for the builder
+    const v16 *ex01, *ex23, *ey01, *ey23;  // HERD: the herd's own planes
+    const uint64_t *dlo, *dhi;             // HERD: its distance words
+    const DpRecord *recs;                  // RECS
+    unsigned long long *result;            // [0] mismatches, [1] indices recorded, [2 .. 2+cap) the first mismatching indices
+    uint32_t cap;
+};
+
+template <bool RECS>
+KNG_DEV v16 audit_distance(const AuditArgs &a, size_t idx) {
+    if (RECS) return *reinterpret_cast<const v16 *>(a.recs[idx].d);
+    return make_ulonglong2(a.dlo[idx], a.dhi[idx]);
+}
+KNG_DEV void audit_report(const AuditArgs &a, size_t idx) {
+    atomicAdd(a.result, 1ULL);
+    const unsigned long long slot = atomicAdd(a.result + 1, 1ULL);
+    if (slot < a.cap) a.result[2 + slot] = (unsigned long long)idx;
+}
+
+template <bool RECS>
+__global__ void __launch_bounds__(256) kng_audit_kernel(const AuditArgs a) {
+    const HerdArgs &h = a.h;
+    const size_t L = h.lanes;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= L || t >= h.n_kang) return;
+    const uint32_t G = (uint32_t)((h.n_kang - t + L - 1) / L);
+    const uint32_t nsteps = h.windows + 1;
+
+    // pass 0: start points, products of the first window's dx
+    fe acc = fe_one();
+    for (uint32_t g = 0; g < G; g++) {
+        const size_t idx = (size_t)g * L + t;
+        const v16 d = audit_distance<RECS>(a, idx);
+        const uint64_t *b = h.base[(RECS ? a.recs[idx].kidx : (uint64_t)idx) & 1];
+        const fe x{{b[0], b[1], b[2], b[3]}}, y{{b[4], b[5], b[6], b[7]}};
+        st_fe(h.x01, h.x23, idx, x);
+        st_fe(h.y01, h.y23, idx, y);
+        fe qx, qy;
+        const bool on = herd_addend(h, 0, d, qx, qy) && (d.x | d.y) != 0;
+        const fe dx = on ? fe_sub(x, qx) : fe_one();
+        acc = g ? fe_mul(acc, dx) : dx;
+        st_fe(h.s01, h.s23, idx, acc);
+    }
+    for (uint32_t step = 0; step < nsteps; step++) {
+        fe inv = fe_inv(acc);
+        const bool backward = !(step & 1);
+        const bool last = (step + 1 == nsteps);
+        auto slot = [&](uint32_t k) -> size_t { return (size_t)(backward ? (G - 1 - k) : k) * L + t; };
+        for (uint32_t k = 0; k < G; k++) {
+            const size_t idx = slot(k);
+            const fe cx = ld_fe(h.x01, h.x23, idx), cy = ld_fe(h.y01, h.y23, idx);
+            const v16 d = audit_distance<RECS>(a, idx);
+            const bool live = (d.x | d.y) != 0;
+            fe qx, qy;
+            const bool on = herd_addend(h, step, d, qx, qy) && live;
+            const fe dx = on ? fe_sub(cx, qx) : fe_one();
+            fe invk;
+            if (k + 1 < G) {
+                invk = fe_mul(inv, ld_fe(h.s01, h.s23, slot(k + 1)));
+                inv = fe_mul(inv, dx);
+            } else {
+                invk = inv;
+            }
+            fe rx = cx, ry = cy;
+            if (on) { // P + Q, affine: the builder's formulas
+                const fe s = fe_mul(fe_sub(cy, qy), invk);
+                rx = fe_sub(fe_sub(fe_sqr(s), qx), cx);
+                ry = fe_sub(fe_mul(fe_sub(cx, rx), s), cy);
+                if (!last) {
+                    st_fe(h.x01, h.x23, idx, rx);
+                    st_fe(h.y01, h.y23, idx, ry);
+                }
+            }
+            if (last) {
+                rx = fe_canon(rx);
+                ry = fe_canon(ry);
+                bool ok = live;
+                if (RECS) {
+                    const DpRecord &r = a.recs[idx];
+                    if (r.pad == 0) {
+                        const fe ex = fe_canon(fe{{r.x[0], r.x[1], r.x[2], r.x[3]}});
+                        ok = ok && ex.v[0] == rx.v[0] && ex.v[1] == rx.v[1] && ex.v[2] == rx.v[2] && ex.v[3] == rx.v[3];
+                    } else { // what a hash-table entry keeps: x limbs 0-1 and the bucket bits of limb 2
+                        ok = ok && r.x[0] == rx.v[0] && r.x[1] == rx.v[1] && ((r.x[2] ^ rx.v[2]) & 0x3FFFFULL) == 0;
+                    }
+                } else {
+                    const fe ex = fe_canon(ld_fe(a.ex01, a.ex23, idx)), ey = fe_canon(ld_fe(a.ey01, a.ey23, idx));
+                    for (int i = 0; i < 4; i++) ok = ok && ex.v[i] == rx.v[i] && ey.v[i] == ry.v[i];
+                }
+                if (!ok) audit_report(a, idx);
+            } else {
+                fe nqx, nqy;
+                const bool non = herd_addend(h, step + 1, d, nqx, nqy) && live;
+                const fe dx2 = non ? fe_sub(rx, nqx) : fe_one();
+                acc = k ? fe_mul(acc, dx2) : dx2;
+                st_fe(h.s01, h.s23, idx, acc);
+            }
+        }
+    }
+}
+
 // overwrite one kangaroo, stream-ordered (replaces the ten 8-byte copies of GPUEngine.cu:504-530)
 __global__ void kng_patch_kernel(v16 *x01, v16 *x23, v16 *y01, v16 *y23, v16 *d, uint64_t n, uint64_t idx, fe x,
                                  fe y, v16 dd) {
@@ -644,6 +758,13 @@ struct kng_engine {
     uint32_t last_exact_exits = 0; // wave-iterations the scheduled loop handed to the general arithmetic in the last waited launch
     bool lost_warned = false;
     uint64_t bytes = 0;
+    // whole-run audit (kng_audit_*): window table + offset points on the device, result block (device + pinned)
+    uint64_t *audit_tab = nullptr;
+    uint64_t audit_base[2][8] = {{0}}, audit_fin[8] = {0};
+    unsigned long long *audit_res = nullptr, *audit_res_host = nullptr;
+    bool audit_ready = false;
+    float last_audit_ms = 0.f;
+    WalkAsmArgs *asm_args_host = nullptr; // pinned staging of the loop constants: uploaded stream-ordered (kng_set_params)
 };
 
 static inline v16 *plane(const kng_engine *h, int k) { return h->planes + (size_t)k * h->n; }
@@ -656,9 +777,12 @@ static void decide_dsplit(kng_engine *h) {
     h->dsplit_on = possible && (h->dsplit == 1 || (h->dsplit == -1 && h->jd_max < (1ULL << (h->use_asm ? 58 : 50))));
 }
 static DpRecord *dp_buffer(const kng_engine *h, int s) { return h->dp_ring ? h->ring_dev[s] : h->dp_items[s]; }
-// constants of the scheduled loop (WalkAsmArgs), one block per DP buffer; stream-ordered behind any in-flight launch
+// constants of the scheduled loop (WalkAsmArgs), one block per DP buffer.  Uploaded from a pinned block with a copy on the
+// WALK stream: ordered behind a launch in flight (whose loop re-reads them at every entry) and ahead of the next one --
+// the reference's cudaMemcpyToSymbol blocks behind its kernel the same way (GPUEngine.cu:565-583).  The caller
+// synchronises the stream before the pinned block is reused.
 static int upload_loop_args(kng_engine *h) {
-    WalkAsmArgs aa[2];
+    WalkAsmArgs *aa = h->asm_args_host;
     for (int s = 0; s < 2; s++) {
         aa[s].x01 = (uint64_t)plane(h, 0); aa[s].x23 = (uint64_t)plane(h, 1); aa[s].y01 = (uint64_t)plane(h, 2); aa[s].y23 = (uint64_t)plane(h, 3);
         aa[s].dlo = (uint64_t)dplane(h, 0); aa[s].dhi = (uint64_t)dplane(h, 1);
@@ -666,8 +790,83 @@ static int upload_loop_args(kng_engine *h) {
         aa[s].dp_mask = h->dp_mask; aa[s].dp_count = (uint64_t)h->dp_count[s]; aa[s].dp_items = (uint64_t)dp_buffer(h, s);
         aa[s].max_found = h->max_found; aa[s].pad = 0;
     }
-    HIP_TRY(hipMemcpy(h->asm_args, aa, sizeof aa, hipMemcpyHostToDevice)); // tiny and synchronous: `aa` lives on this stack
+    HIP_TRY(hipMemcpyAsync(h->asm_args, aa, 2 * sizeof(WalkAsmArgs), hipMemcpyHostToDevice, h->walk));
+    HIP_TRY(hipStreamSynchronize(h->walk));
     return KNG_OK;
+}
+
+// DP landing buffers by mode (option "dp_ring"): the pinned rings the kernel writes directly, or the device buffers +
+// the pinned landing buffer of the copy path -- never both (a solver may ask for 4e8 slots = 25.6 GB per buffer)
+static int alloc_dp_buffers(kng_engine *h) {
+    const size_t bytes = (size_t)h->max_found * sizeof(DpRecord);
+    hipError_t e;
+    if (h->dp_ring) {
+        for (int s = 0; s < 2; s++) {
+            if (h->ring[s]) continue;
+            if ((e = hipHostMalloc((void **)&h->ring[s], bytes, hipHostMallocMapped | hipHostMallocPortable)) != hipSuccess)
+                return fail(KNG_E_ALLOC, "pinned DP ring (%zu bytes): %s", bytes, hipGetErrorString(e));
+            if ((e = hipHostGetDevicePointer((void **)&h->ring_dev[s], h->ring[s], 0)) != hipSuccess)
+                return fail(KNG_E_HIP, "device view of the DP ring: %s", hipGetErrorString(e));
+        }
+    } else {
+        for (int s = 0; s < 2; s++) {
+            if (h->dp_items[s]) continue;
+            if ((e = hipMalloc((void **)&h->dp_items[s], bytes)) != hipSuccess) return fail(KNG_E_ALLOC, "dp items (%zu bytes): %s", bytes, hipGetErrorString(e));
+        }
+        if (!h->h_items && (e = hipHostMalloc((void **)&h->h_items, bytes, hipHostMallocDefault)) != hipSuccess)
+            return fail(KNG_E_ALLOC, "pinned dp items (%zu bytes): %s", bytes, hipGetErrorString(e));
+    }
+    return KNG_OK;
+}
+static void free_dp_buffers(kng_engine *h, bool rings) {
+    if (rings) {
+        for (int s = 0; s < 2; s++) {
+            if (h->ring[s]) (void)hipHostFree(h->ring[s]);
+            h->ring[s] = h->ring_dev[s] = nullptr;
+        }
+    } else {
+        for (int s = 0; s < 2; s++) {
+            if (h->dp_items[s]) (void)hipFree(h->dp_items[s]);
+            h->dp_items[s] = nullptr;
+        }
+        if (h->h_items) (void)hipHostFree(h->h_items);
+        h->h_items = nullptr;
+    }
+}
+
+#define KNG_AUDIT_CAP 1024 // mismatching indices kept per audit launch
+// one audit launch over `n` items on `stream`; scratch = 6 planes of n vectors (x', y', products)
+template <bool RECS>
+static int run_audit(kng_engine *h, hipStream_t stream, AuditArgs &a, v16 *scratch, v16 *s01, v16 *s23, uint64_t n, uint32_t lanes, uint64_t *n_bad,
+                     uint64_t *bad_idx, uint32_t bad_cap, uint64_t idx_offset, uint32_t *recorded) {
+    a.h.x01 = scratch; a.h.x23 = scratch + n; a.h.y01 = scratch + 2 * n; a.h.y23 = scratch + 3 * n;
+    a.h.d = nullptr; a.h.s01 = s01; a.h.s23 = s23;
+    a.h.table = h->audit_tab;
+    memcpy(a.h.base, h->audit_base, sizeof a.h.base);
+    memcpy(a.h.fin, h->audit_fin, sizeof a.h.fin);
+    a.h.seed = 0; a.h.n_kang = n; a.h.windows = KNG_AUDIT_WINDOWS; a.h.range_power = 128; a.h.lanes = lanes;
+    a.result = h->audit_res; a.cap = KNG_AUDIT_CAP;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return fail(KNG_E_HIP, "event creation failed"); }
+    int rc = KNG_OK;
+    do {
+        hipError_t e;
+        if ((e = hipMemsetAsync(h->audit_res, 0, (2 + KNG_AUDIT_CAP) * 8, stream)) != hipSuccess || (e = hipEventRecord(e0, stream)) != hipSuccess) { rc = fail(KNG_E_HIP, "audit: %s", hipGetErrorString(e)); break; }
+        hipLaunchKernelGGL((kng_audit_kernel<RECS>), dim3((lanes + 255) / 256), dim3(256), 0, stream, a);
+        if ((e = hipGetLastError()) != hipSuccess || (e = hipEventRecord(e1, stream)) != hipSuccess ||
+            (e = hipMemcpyAsync(h->audit_res_host, h->audit_res, (2 + KNG_AUDIT_CAP) * 8, hipMemcpyDeviceToHost, stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(stream)) != hipSuccess) { rc = fail(KNG_E_HIP, "audit kernel: %s", hipGetErrorString(e)); break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        h->last_audit_ms += ms;
+        *n_bad += h->audit_res_host[0];
+        const uint64_t got = h->audit_res_host[1] < KNG_AUDIT_CAP ? h->audit_res_host[1] : KNG_AUDIT_CAP;
+        for (uint64_t i = 0; i < got && bad_idx && *recorded < bad_cap; i++) bad_idx[(*recorded)++] = idx_offset + h->audit_res_host[2 + i];
+    } while (0);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
 }
 
 extern "C" {
@@ -691,6 +890,16 @@ int kng_device_info(int dev, char *name, size_t name_cap, int *cu_count, uint64_
     if (arch && arch_cap) snprintf(arch, arch_cap, "%s", p.gcnArchName);
     if (cu_count) *cu_count = p.multiProcessorCount;
     if (mem_bytes) *mem_bytes = (uint64_t)p.totalGlobalMem;
+    return KNG_OK;
+}
+
+int kng_device_free_bytes(int dev, uint64_t *free_bytes, uint64_t *total_bytes) {
+    if (dev < 0 || dev >= kng_device_count()) return fail(KNG_E_NODEVICE, "invalid device %d", dev);
+    HIP_TRY(hipSetDevice(dev));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (uint64_t)f;
+    if (total_bytes) *total_bytes = (uint64_t)t;
     return KNG_OK;
 }
 
@@ -757,10 +966,10 @@ int kng_create(int dev, int grid_x, int grid_y, uint32_t max_found, kng_engine *
     if ((e = hipMalloc((void **)&h->asm_args, 2 * sizeof(WalkAsmArgs))) != hipSuccess) return bail(fail(KNG_E_ALLOC, "loop arguments: %s", hipGetErrorString(e)));
     // the scheduled loop addresses a plane as base + 32-bit byte offset and a DP record as base + 32-bit offset
     if (h->n > (1ull << 28) || max_found > (1u << 26)) h->use_asm = 0;
+    if ((e = hipHostMalloc((void **)&h->asm_args_host, 2 * sizeof(WalkAsmArgs), hipHostMallocDefault)) != hipSuccess)
+        return bail(fail(KNG_E_ALLOC, "pinned loop arguments: %s", hipGetErrorString(e)));
     for (int s = 0; s < 2; s++) {
         if ((e = hipMalloc((void **)&h->dp_count[s], 64)) != hipSuccess) return bail(fail(KNG_E_ALLOC, "dp counter: %s", hipGetErrorString(e)));
-        if ((e = hipMalloc((void **)&h->dp_items[s], (size_t)max_found * sizeof(DpRecord))) != hipSuccess)
-            return bail(fail(KNG_E_ALLOC, "dp items: %s", hipGetErrorString(e)));
         // zero at allocation: the reference reads an uninitialised counter on its first Launch
         if ((e = hipMemset(h->dp_count[s], 0, 64)) != hipSuccess) return bail(fail(KNG_E_HIP, "memset: %s", hipGetErrorString(e)));
         if ((e = hipHostMalloc((void **)&h->h_count[s], 64, hipHostMallocDefault)) != hipSuccess)
@@ -770,21 +979,15 @@ int kng_create(int dev, int grid_x, int grid_y, uint32_t max_found, kng_engine *
             hipEventCreateWithFlags(&h->ev_done[s], hipEventBlockingSync) != hipSuccess)
             return bail(fail(KNG_E_HIP, "event creation failed"));
     }
-    if ((e = hipHostMalloc((void **)&h->h_items, (size_t)max_found * sizeof(DpRecord), hipHostMallocDefault)) != hipSuccess)
-        return bail(fail(KNG_E_ALLOC, "pinned dp items: %s", hipGetErrorString(e)));
-    for (int s = 0; s < 2; s++) { // the DP ring: pinned host memory the kernel writes directly (option "dp_ring")
-        if ((e = hipHostMalloc((void **)&h->ring[s], (size_t)max_found * sizeof(DpRecord), hipHostMallocMapped | hipHostMallocPortable)) != hipSuccess)
-            return bail(fail(KNG_E_ALLOC, "pinned DP ring (%zu bytes): %s", (size_t)max_found * sizeof(DpRecord), hipGetErrorString(e)));
-        if ((e = hipHostGetDevicePointer((void **)&h->ring_dev[s], h->ring[s], 0)) != hipSuccess)
-            return bail(fail(KNG_E_HIP, "device view of the DP ring: %s", hipGetErrorString(e)));
-    }
+    // DP landing buffers of the mode in use only (default: the pinned rings); the other kind when "dp_ring" is switched
+    if (int rc = alloc_dp_buffers(h)) return bail(rc);
     h->stage_kang = h->n < (1u << 16) ? (size_t)h->n : (size_t)(1u << 16);
     if ((e = hipHostMalloc((void **)&h->h_stage, 6 * h->stage_kang * sizeof(v16), hipHostMallocDefault)) != hipSuccess)
         return bail(fail(KNG_E_ALLOC, "pinned staging: %s", hipGetErrorString(e)));
     if (hipStreamCreateWithFlags(&h->walk, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking) != hipSuccess)
         return bail(fail(KNG_E_HIP, "stream creation failed"));
-    h->bytes = state_bytes + JT_WORDS * 8 + 2 * (64 + (uint64_t)max_found * sizeof(DpRecord));
+    h->bytes = state_bytes + JT_WORDS * 8 + 2 * 64 + (h->dp_ring ? 0 : 2 * (uint64_t)max_found * sizeof(DpRecord)); // device memory (GetMemory())
     *out = h;
     return KNG_OK;
 }
@@ -799,15 +1002,17 @@ void kng_destroy(kng_engine *h) {
     if (h->asm_args) (void)hipFree(h->asm_args);
     for (int s = 0; s < 2; s++) {
         if (h->dp_count[s]) (void)hipFree(h->dp_count[s]);
-        if (h->dp_items[s]) (void)hipFree(h->dp_items[s]);
         if (h->h_count[s]) (void)hipHostFree(h->h_count[s]);
         if (h->ev_start[s]) (void)hipEventDestroy(h->ev_start[s]);
         if (h->ev_stop[s]) (void)hipEventDestroy(h->ev_stop[s]);
         if (h->ev_done[s]) (void)hipEventDestroy(h->ev_done[s]);
     }
-    if (h->h_items) (void)hipHostFree(h->h_items);
-    for (int s = 0; s < 2; s++)
-        if (h->ring[s]) (void)hipHostFree(h->ring[s]);
+    free_dp_buffers(h, true);
+    free_dp_buffers(h, false);
+    if (h->asm_args_host) (void)hipHostFree(h->asm_args_host);
+    if (h->audit_tab) (void)hipFree(h->audit_tab);
+    if (h->audit_res) (void)hipFree(h->audit_res);
+    if (h->audit_res_host) (void)hipHostFree(h->audit_res_host);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->walk) (void)hipStreamDestroy(h->walk);
     if (h->copy) (void)hipStreamDestroy(h->copy);
@@ -841,19 +1046,24 @@ int kng_set_option(kng_engine *h, const char *key, int64_t value) {
         h->dsplit = (int)value;
         decide_dsplit(h);
     } else if (k == "share") {
-        if (value != 1 && value != 8) return fail(KNG_E_ARG, "share must be 1 (every wave inverts) or 8 (one inversion per CU)");
+        if (value != 8) return fail(KNG_E_ARG, "share must be 8 (one inversion per CU; the every-wave-inverts form of rounds 1-3 was removed)");
         h->share = (int)value;
     } else if (k == "dp_ring") {
         if (value < 0 || value > 1) return fail(KNG_E_ARG, "dp_ring must be 0 or 1");
+        if ((int)value == h->dp_ring) return KNG_OK;
+        // points of a launch that was waited for but not drained live in the buffers about to be released
+        if (h->slot_ready >= 0) return fail(KNG_E_STATE, "drain the points of the last waited launch before switching dp_ring");
         HIP_TRY(hipSetDevice(h->dev));
-        for (int s = 0; value && s < 2; s++) {
-            if (h->ring[s]) continue;
-            hipError_t e = hipHostMalloc((void **)&h->ring[s], (size_t)h->max_found * sizeof(DpRecord), hipHostMallocMapped | hipHostMallocPortable);
-            if (e != hipSuccess) return fail(KNG_E_ALLOC, "pinned DP ring (%zu bytes): %s", (size_t)h->max_found * sizeof(DpRecord), hipGetErrorString(e));
-            HIP_TRY(hipHostGetDevicePointer((void **)&h->ring_dev[s], h->ring[s], 0));
-        }
+        const int before = h->dp_ring;
         h->dp_ring = (int)value;
-        h->slot_ready = -1; // points of a launch waited for but not yet drained live in the other kind of buffer
+        if (int rc = alloc_dp_buffers(h)) {
+            free_dp_buffers(h, h->dp_ring != 0); // whatever part of the new kind was obtained
+            h->dp_ring = before;
+            return rc;
+        }
+        free_dp_buffers(h, before != 0);
+        h->view = nullptr;
+        h->bytes = 7 * (uint64_t)h->n * sizeof(v16) + JT_WORDS * 8 + 2 * 64 + (h->dp_ring ? 0 : 2 * (uint64_t)h->max_found * sizeof(DpRecord));
         if (h->have_params) {
             int rc = upload_loop_args(h);
             if (rc != KNG_OK) return rc;
@@ -882,6 +1092,7 @@ int kng_get_option(const kng_engine *h, const char *key, int64_t *value) {
     else if (k == "dsplit") *value = h->dsplit_on ? 1 : 0;
     else if (k == "exact_exits") *value = h->last_exact_exits;
     else if (k == "cu_count") *value = h->cu_count;
+    else if (k == "audit_us") *value = (int64_t)(h->last_audit_ms * 1000.0f + 0.5f);
     else if (k == "waves_per_cu") *value = h->cu_count ? (int64_t)((h->lanes / 64 + h->cu_count - 1) / h->cu_count) : 0;
     else return fail(KNG_E_ARG, "unknown option '%s'", key);
     return KNG_OK;
@@ -911,11 +1122,12 @@ int kng_set_params(kng_engine *h, uint64_t dp_mask, const uint64_t *jd, const ui
         fprintf(stderr, "kng: planes %p..%p (n=%llu) jtab %p asm_args %p dp_count %p %p dp_items %p %p max_found %u\n", (void *)h->planes,
                 (void *)(h->planes + 7 * h->n), (unsigned long long)h->n, (void *)h->jtab, (void *)h->asm_args, (void *)h->dp_count[0],
                 (void *)h->dp_count[1], (void *)h->dp_items[0], (void *)h->dp_items[1], h->max_found);
-    // stream-ordered after any in-flight launch
+    // Both uploads are copies on the walk stream: a launch in flight finishes with the table and mask it started with
+    // (its loop re-reads WalkAsmArgs at every entry), the next launch sees the new ones; the call returns when they have
+    // landed, i.e. it blocks behind a running kernel like the reference's cudaMemcpyToSymbol (GPUEngine.cu:565-583).
     HIP_TRY(hipMemcpyAsync(h->jtab, tab, sizeof tab, hipMemcpyHostToDevice, h->walk));
-    int rc = upload_loop_args(h);
+    int rc = upload_loop_args(h); // (synchronises the stream: `tab` lives on this stack)
     if (rc != KNG_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(h->walk));
     h->have_params = true;
     return KNG_OK;
 }
@@ -1026,6 +1238,80 @@ int kng_build_herd(kng_engine *h, int range_power, uint64_t seed, const uint64_t
     return KNG_OK;
 }
 
+// ---- whole-run audit: every kangaroo / every DP record re-derived from its distance (kng_audit_kernel) ----
+
+int kng_audit_setup(kng_engine *h, const uint64_t *table, const uint64_t base_tame[8], const uint64_t base_wild[8], const uint64_t final_add[8]) {
+    if (!h || !table || !base_tame || !base_wild || !final_add) return fail(KNG_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->dev));
+    const size_t tbytes = (size_t)KNG_AUDIT_WINDOWS * 256 * 8 * sizeof(uint64_t);
+    hipError_t e;
+    if (!h->audit_tab && (e = hipMalloc((void **)&h->audit_tab, tbytes)) != hipSuccess) return fail(KNG_E_ALLOC, "audit table: %s", hipGetErrorString(e));
+    if (!h->audit_res && (e = hipMalloc((void **)&h->audit_res, (2 + KNG_AUDIT_CAP) * 8)) != hipSuccess) return fail(KNG_E_ALLOC, "audit result: %s", hipGetErrorString(e));
+    if (!h->audit_res_host && (e = hipHostMalloc((void **)&h->audit_res_host, (2 + KNG_AUDIT_CAP) * 8, hipHostMallocDefault)) != hipSuccess)
+        return fail(KNG_E_ALLOC, "pinned audit result: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpy(h->audit_tab, table, tbytes, hipMemcpyHostToDevice));
+    memcpy(h->audit_base[0], base_tame, 64);
+    memcpy(h->audit_base[1], base_wild, 64);
+    memcpy(h->audit_fin, final_add, 64);
+    h->audit_ready = true;
+    return KNG_OK;
+}
+
+int kng_audit_herd(kng_engine *h, uint64_t *n_bad, uint64_t *bad_idx, uint32_t bad_cap) {
+    if (!h || !n_bad) return fail(KNG_E_ARG, "null argument");
+    *n_bad = 0;
+    if (!h->audit_ready) return fail(KNG_E_STATE, "kng_audit_setup has not been called");
+    if (!h->have_herd) return fail(KNG_E_STATE, "no herd loaded");
+    if (h->outstanding) return fail(KNG_E_STATE, "a launch is outstanding (the audit borrows the walk's product planes)");
+    HIP_TRY(hipSetDevice(h->dev));
+    DevBuf scratch;
+    hipError_t e = scratch.alloc(4 * (size_t)h->n * sizeof(v16));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(KNG_E_ALLOC, "audit scratch (%zu bytes): %s", 4 * (size_t)h->n * sizeof(v16), hipGetErrorString(e));
+    }
+    AuditArgs a{};
+    a.ex01 = plane(h, 0); a.ex23 = plane(h, 1); a.ey01 = plane(h, 2); a.ey23 = plane(h, 3);
+    a.dlo = dplane(h, 0); a.dhi = dplane(h, 1);
+    a.recs = nullptr;
+    h->last_audit_ms = 0.f;
+    uint32_t recorded = 0;
+    // the S planes are free between launches: every launch starts with its own product pass
+    return run_audit<false>(h, h->walk, a, scratch.as<v16>(), plane(h, 5), plane(h, 6), h->n, h->lanes, n_bad, bad_idx, bad_cap, 0, &recorded);
+}
+
+int kng_audit_points(kng_engine *h, const kng_dp_record *recs, uint64_t n, uint64_t *n_bad, uint64_t *bad_idx, uint32_t bad_cap) {
+    if (!h || !n_bad || (!recs && n)) return fail(KNG_E_ARG, "null argument");
+    *n_bad = 0;
+    if (!h->audit_ready) return fail(KNG_E_STATE, "kng_audit_setup has not been called");
+    if (n == 0) return KNG_OK;
+    HIP_TRY(hipSetDevice(h->dev));
+    const uint64_t C = n < (1ull << 21) ? n : (1ull << 21); // records per launch
+    DevBuf scratch, drec;
+    hipError_t e;
+    if ((e = scratch.alloc(6 * (size_t)C * sizeof(v16))) != hipSuccess || (e = drec.alloc((size_t)C * sizeof(DpRecord))) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(KNG_E_ALLOC, "audit scratch for %llu records: %s", (unsigned long long)C, hipGetErrorString(e));
+    }
+    h->last_audit_ms = 0.f;
+    uint32_t recorded = 0;
+    // own stream: the records need nothing of the herd, so a walk launch in flight is not disturbed
+    for (uint64_t c0 = 0; c0 < n; c0 += C) {
+        const uint64_t m = n - c0 < C ? n - c0 : C;
+        HIP_TRY(hipMemcpyAsync(drec.p, recs + c0, (size_t)m * sizeof(DpRecord), hipMemcpyHostToDevice, h->copy));
+        // batch of ~32 per lane, at most two waves per SIMD
+        uint64_t lanes = ((m + 31) / 32 + 63) / 64 * 64;
+        const uint64_t most = (uint64_t)h->cu_count * 512;
+        if (lanes > most) lanes = most;
+        AuditArgs a{};
+        a.recs = drec.as<DpRecord>();
+        v16 *sc = scratch.as<v16>();
+        int rc = run_audit<true>(h, h->copy, a, sc, sc + 4 * m, sc + 5 * m, m, (uint32_t)lanes, n_bad, bad_idx, bad_cap, c0, &recorded);
+        if (rc != KNG_OK) return rc;
+    }
+    return KNG_OK;
+}
+
 int kng_set_kangaroo(kng_engine *h, uint64_t kidx, const uint64_t x[4], const uint64_t y[4], const uint64_t d[2]) {
     if (!h || !x || !y || !d) return fail(KNG_E_ARG, "null argument");
     if (kidx >= h->n) return fail(KNG_E_ARG, "kIdx %llu out of range", (unsigned long long)kidx);
@@ -1059,17 +1345,13 @@ int kng_launch(kng_engine *h) {
     a.asm_args = (uint64_t)(h->asm_args + s);
     HIP_TRY(hipMemsetAsync(h->dp_count[s], 0, 8, h->walk)); // GPUEngine.cu:543 (+ the launch's exact-path exit counter)
     HIP_TRY(hipEventRecord(h->ev_start[s], h->walk));
-    const uint32_t blocks = (h->lanes + h->block - 1) / h->block;
     const bool ds = h->dsplit_on;
-    const dim3 grid2((h->lanes + 511) / 512), grid1(blocks);
+    const dim3 grid2((h->lanes + 511) / 512);
 #define KNG_LAUNCH(SH, DS, AS, GRID, BLOCK) hipLaunchKernelGGL((kng_walk_share_kernel<SH, DS, AS>), GRID, dim3(BLOCK), 0, h->walk, a)
-    if (h->share == 8) { // one inversion per CU
-        if (h->use_asm) { if (ds) KNG_LAUNCH(8, true, true, grid2, 512); else KNG_LAUNCH(8, false, true, grid2, 512); }
-        else { if (ds) KNG_LAUNCH(8, true, false, grid2, 512); else KNG_LAUNCH(8, false, false, grid2, 512); }
-    } else {
-        if (h->use_asm) { if (ds) KNG_LAUNCH(1, true, true, grid1, h->block); else KNG_LAUNCH(1, false, true, grid1, h->block); }
-        else { if (ds) KNG_LAUNCH(1, true, false, grid1, h->block); else KNG_LAUNCH(1, false, false, grid1, h->block); }
-    }
+    // four instantiations: the scheduled loop for either distance layout, and the compiler-scheduled pair that serves herds
+    // beyond 2^28 kangaroos (and is the exact path behind the scheduled loop).  Round 1-3's share = 1 family is gone.
+    if (h->use_asm) { if (ds) KNG_LAUNCH(8, true, true, grid2, 512); else KNG_LAUNCH(8, false, true, grid2, 512); }
+    else { if (ds) KNG_LAUNCH(8, true, false, grid2, 512); else KNG_LAUNCH(8, false, false, grid2, 512); }
 #undef KNG_LAUNCH
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev_stop[s], h->walk));

@@ -27,6 +27,7 @@ _LIB_PATH = os.path.join(_PKG, "lib", "libkangaroo_hip.so")
 _U64P = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 
 ITEM_DTYPE = np.dtype([("x", np.uint64, 4), ("d", np.uint64, 2), ("kidx", np.uint64)])
+RECORD_DTYPE = np.dtype([("x", np.uint64, 4), ("d", np.uint64, 2), ("kidx", np.uint64), ("reserved", np.uint64)])  # kng_dp_record
 
 
 class EngineError(RuntimeError):
@@ -73,9 +74,15 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.kng_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.kng_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
     L.kng_test_fieldop.argtypes = [C.c_int, C.c_int, _U64P, _U64P, _U64P, C.c_uint64]
+    L.kng_audit_setup.argtypes = [C.c_void_p, _U64P, _U64P, _U64P, _U64P]
+    L.kng_audit_herd.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint32]
+    L.kng_audit_points.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint32]
+    L.kng_drain_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.kng_outstanding.argtypes = [C.c_void_p]
     for name in ("kng_device_info", "kng_default_grid", "kng_create", "kng_set_params", "kng_set_kangaroos",
                  "kng_get_kangaroos", "kng_set_kangaroos_range", "kng_get_kangaroos_range", "kng_set_kangaroo", "kng_launch", "kng_wait", "kng_drain",
-                 "kng_last_kernel_ms", "kng_set_option", "kng_get_option", "kng_test_fieldop"):
+                 "kng_last_kernel_ms", "kng_set_option", "kng_get_option", "kng_test_fieldop", "kng_audit_setup", "kng_audit_herd",
+                 "kng_audit_points", "kng_drain_view", "kng_outstanding"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -98,6 +105,15 @@ def device_info(dev: int = 0) -> dict:
     mem = C.c_uint64(0)
     _check(L.kng_device_info(dev, name, 256, C.byref(cu), C.byref(mem), arch, 256))
     return {"name": name.value.decode(), "arch": arch.value.decode(), "cu_count": cu.value, "mem_bytes": mem.value}
+
+
+def device_free_bytes(dev: int = 0) -> tuple:
+    """(free, total) device memory in bytes (kng_device_free_bytes)."""
+    L = load_library()
+    L.kng_device_free_bytes.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    _check(L.kng_device_free_bytes(dev, C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
 
 
 def default_grid(dev: int = 0, x: int = 0, y: int = 0) -> tuple:
@@ -324,3 +340,42 @@ class GPUEngine:
         v = C.c_int64(0)
         _check(self._L.kng_get_option(self._h, key.encode(), C.byref(v)))
         return v.value
+
+    # -- whole-run audit (kng_audit_*) ------------------------------------------------------------
+    def audit_setup(self, key_xy=None, seed: int = 0xA0D17, wild_offset: int | None = None) -> None:
+        """Upload the inputs of the device audit for this key: the 16-window table of G and the offset points
+        (hostlib.herd_params at 128 bits).  key_xy = the (shifted) public key the wild herd walks from; the wild offset
+        defaults to the one SetWildOffset / CreateHerdOnDevice left."""
+        from . import hostlib
+
+        woff = self.wildOffset if wild_offset is None else wild_offset
+        table, windows, bt, bw, fin = hostlib.audit_params(key_xy, woff, seed)
+        assert windows == 16
+        _check(self._L.kng_audit_setup(self._h, table, bt, bw, fin))
+
+    def audit_herd(self, cap: int = 16):
+        """(mismatches, first mismatching kIdx ...): every kangaroo re-derived from its device distance, x and y compared."""
+        bad = C.c_uint64(0)
+        idx = np.zeros(max(cap, 1), np.uint64)
+        _check(self._L.kng_audit_herd(self._h, C.byref(bad), idx.ctypes.data, cap))
+        return int(bad.value), [int(v) for v in idx[: min(cap, bad.value)]]
+
+    def audit_points(self, records: np.ndarray, cap: int = 16):
+        """(mismatches, first mismatching positions): records of RECORD_DTYPE (reserved = 0: full x, 1: table-entry bits)."""
+        assert records.dtype == RECORD_DTYPE and records.flags.c_contiguous
+        bad = C.c_uint64(0)
+        idx = np.zeros(max(cap, 1), np.uint64)
+        _check(self._L.kng_audit_points(self._h, records.ctypes.data, len(records), C.byref(bad), idx.ctypes.data, cap))
+        return int(bad.value), [int(v) for v in idx[: min(cap, bad.value)]]
+
+    def drain_records(self) -> np.ndarray:
+        """kng_drain_view: the 64-byte records of the most recently waited launch, copied out of the landing buffer."""
+        p = C.c_void_p()
+        n = C.c_uint32(0)
+        lost = C.c_uint32(0)
+        _check(self._L.kng_drain_view(self._h, C.byref(p), C.byref(n), C.byref(lost)))
+        self.lastLost = lost.value
+        if not n.value:
+            return np.zeros(0, RECORD_DTYPE)
+        buf = (C.c_char * (n.value * RECORD_DTYPE.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=RECORD_DTYPE).copy()

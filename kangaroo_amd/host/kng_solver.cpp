@@ -126,6 +126,7 @@ struct kngs_solver {
     // counters
     std::atomic<uint64_t> dps{0}, dps_lost{0}, same_herd{0}, wrong{0};
     uint64_t offset_count = 0;
+    uint64_t warmup_jumps = 0; // part of offset_count: jumps of the discarded warm-up launches (kngs_prepare)
     double offset_seconds = 0;
     Clock::time_point t_start;
     double run_seconds = 0; // frozen at stop
@@ -135,6 +136,7 @@ struct kngs_solver {
     uint64_t herd_left = 0, herd_total = 0;
     bool herd_spent = false; // a failed kngs_prepare had already taken kangaroos from the work file
     uint64_t herd_loaded = 0, herd_created = 0;
+    uint64_t audits = 0, audited_kangaroos = 0, audit_mismatches = 0; // kngs_audit, cumulative
     uint64_t seed_used = 0;
     bool prepared = false;    // engines created, herds in place (kngs_prepare)
     bool ingest_only = false; // kngs_start_ingest: consumers without engines (host-path measurements)
@@ -609,6 +611,7 @@ int kngs_prepare(kngs_solver *s) {
         s->herd_file = nullptr;
     }
     // benchmarks: launches that are run and thrown away before the clock starts (clocks, caches, first-touch)
+    uint64_t warm_jumps = 0;
     for (uint32_t i = 0; i < cfg.warmup_launches; i++) {
         for (Worker *w : s->workers)
             if (kng_launch(w->eng) != KNG_OK) return undo(fail("kng_launch: %s", kng_last_error()));
@@ -617,9 +620,13 @@ int kngs_prepare(kngs_solver *s) {
             uint32_t n_items, n_lost;
             if (kng_wait(w->eng, 0) != KNG_OK || kng_drain_view(w->eng, &rec, &n_items, &n_lost) != KNG_OK)
                 return undo(fail("warm-up launch: %s", kng_last_error()));
-            s->offset_count += w->n * KNG_NB_RUN; // the herd did advance: the saved total must say so
+            warm_jumps += w->n * KNG_NB_RUN;
         }
     }
+    // the herds did advance, so the saved total must say so -- but only once every warm-up launch has succeeded (a retried
+    // kngs_prepare must not count them twice), and as a figure of its own: their distinguished points were thrown away
+    s->offset_count += warm_jumps;
+    s->warmup_jumps = warm_jumps;
     s->prepared = true;
     return 0;
 }
@@ -780,6 +787,10 @@ int kngs_get_stats(const kngs_solver *s, kngs_stats *st) {
     st->herd_loaded = s->herd_loaded;
     st->herd_created = s->herd_created;
     st->table_bytes = s->joined || s->ingest_only ? kngt_memory_bytes(s->table) : 0;
+    st->warmup_jumps = s->warmup_jumps;
+    st->audits = s->audits;
+    st->audited_kangaroos = s->audited_kangaroos;
+    st->audit_mismatches = s->audit_mismatches;
     if (s->ingest_only) st->table_items = kngt_count(s->table); // racy while points are in flight: callers drain first
     return 0;
 }
@@ -789,11 +800,10 @@ int kngs_collision_key(const kngs_solver *s, const uint64_t tame_d[4], const uin
     return resolve(s, tame_d, wild_d, priv) ? 1 : 0;
 }
 
-int kngs_save(kngs_solver *s, const char *path, int with_kangaroos) {
-    if (!s || !path) return fail("null argument");
-    if (!s->started) return fail("not started");
-    std::lock_guard<std::mutex> save_lock(s->save_m);
-    // SaveWork (Backup.cpp:446-470): wait until every thread blocks at a launch boundary
+namespace {
+// SaveWork (Backup.cpp:446-470): wait until every GPU thread blocks at a launch boundary with no kernel in flight and every
+// queued point is in the table.  The engines then belong to the caller until release_workers.
+int park_workers(kngs_solver *s) {
     s->pause_req = 1;
     bool parked;
     {
@@ -815,6 +825,22 @@ int kngs_save(kngs_solver *s, const char *path, int with_kangaroos) {
         return fail("timed out waiting for the GPU threads to reach a launch boundary");
     }
     while (s->inflight.load() && !s->failed) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    return 0;
+}
+void release_workers(kngs_solver *s) {
+    {
+        std::lock_guard<std::mutex> g(s->ctl_m);
+        s->pause_req = 0;
+    }
+    s->ctl_cv.notify_all();
+}
+} // namespace
+
+int kngs_save(kngs_solver *s, const char *path, int with_kangaroos) {
+    if (!s || !path) return fail("null argument");
+    if (!s->started) return fail("not started");
+    std::lock_guard<std::mutex> save_lock(s->save_m);
+    if (park_workers(s) != 0) return -1;
     int rc = 0;
     kngs_stats st;
     kngs_get_stats(s, &st);
@@ -839,11 +865,96 @@ int kngs_save(kngs_solver *s, const char *path, int with_kangaroos) {
         if (kngw_close(f) != 0 && rc == 0) rc = fail("%s", kngw_last_error());
         else if (rc != 0) g_err = keep;
     }
-    {
-        std::lock_guard<std::mutex> g(s->ctl_m);
-        s->pause_req = 0;
+    release_workers(s);
+    return rc;
+}
+
+// Whole-run audit (kng_solver.h): the device re-derives every kangaroo of every herd -- and every entry of the table -- from
+// its distance.  The reference can only do the table half, on the CPU, from a saved file (-wcheck, Check.cpp:141-411).
+int kngs_audit(kngs_solver *s, int with_table, kngs_audit_result *out) {
+    if (!s || !out) return fail("null argument");
+    std::memset(out, 0, sizeof *out);
+    if (s->ingest_only || s->workers.empty()) return fail("no engines to audit with");
+    if (!s->prepared) return fail("not prepared");
+    std::lock_guard<std::mutex> save_lock(s->save_m);
+    const auto t0 = Clock::now();
+    const bool running = s->started && !s->joined;
+    if (running && park_workers(s) != 0) return -1;
+    int rc = 0;
+    // inputs of the device audit: the 16-window table and the offset points of this key (kngh_herd_params at 128 bits)
+    std::vector<uint64_t> table((size_t)KNG_AUDIT_WINDOWS * 256 * 8);
+    uint64_t bt[8], bw[8], fin[8];
+    if (kngh_herd_params(128, s->wild_offset.v, s->skx, s->sky, s->seed_used ^ 0xA0D17ULL, table.data(), bt, bw, fin) != 0)
+        rc = fail("kngh_herd_params failed");
+    for (size_t g = 0; g < s->workers.size() && rc == 0; g++) {
+        Worker *w = s->workers[g];
+        if (kng_outstanding(w->eng)) { // a worker that ended on an error may have left one
+            if (kng_wait(w->eng, 0) != KNG_OK) rc = fail("kng_wait: %s", kng_last_error());
+        }
+        uint64_t bad = 0, idx[8];
+        if (rc == 0 && kng_audit_setup(w->eng, table.data(), bt, bw, fin) != KNG_OK) rc = fail("kng_audit_setup: %s", kng_last_error());
+        if (rc == 0 && kng_audit_herd(w->eng, &bad, idx, 8) != KNG_OK) rc = fail("kng_audit_herd: %s", kng_last_error());
+        if (rc) break;
+        int64_t us = 0;
+        kng_get_option(w->eng, "audit_us", &us);
+        out->herd_ms += (double)us * 1e-3;
+        out->kangaroos += w->n;
+        for (uint64_t i = 0; i < bad && i < 8 && out->n_first_bad < 8; i++) out->first_bad[out->n_first_bad++] = ((uint64_t)g << 56) | idx[i];
+        out->kangaroo_mismatches += bad;
     }
-    s->ctl_cv.notify_all();
+    if (rc == 0 && with_table) {
+        // every table entry back to an engine record: x limbs 0-1 + the bucket bits, device distance, type; compare mode 1
+        const uint64_t C = 1u << 21;
+        std::vector<kng_dp_record> recs;
+        recs.reserve(C);
+        std::vector<kngt_entry> ent;
+        size_t turn = 0;
+        auto flush = [&]() {
+            if (recs.empty() || rc) return;
+            Worker *w = s->workers[turn++ % s->workers.size()];
+            uint64_t bad = 0;
+            if (kng_audit_points(w->eng, recs.data(), recs.size(), &bad, nullptr, 0) != KNG_OK) {
+                rc = fail("kng_audit_points: %s", kng_last_error());
+                return;
+            }
+            int64_t us = 0;
+            kng_get_option(w->eng, "audit_us", &us);
+            out->table_ms += (double)us * 1e-3;
+            out->table_points += recs.size();
+            out->table_mismatches += bad;
+            recs.clear();
+        };
+        for (uint32_t b = 0; b < KNGT_BUCKETS && rc == 0; b++) {
+            const uint32_t cnt = kngt_bucket_count(s->table, b);
+            if (!cnt) continue;
+            ent.resize(cnt);
+            const uint32_t got = kngt_bucket_entries(s->table, b, ent.data(), cnt);
+            for (uint32_t i = 0; i < got; i++) {
+                uint64_t d[4], dd[4];
+                uint32_t type = 0;
+                kngt_decode(ent[i].d, d, &type);
+                if (type & 1) kngh_add_order(d, s->wild_offset.v, dd); else std::memcpy(dd, d, 32);
+                if (dd[2] | dd[3]) { // not a distance an engine can have produced
+                    out->table_points++;
+                    out->table_mismatches++;
+                    continue;
+                }
+                kng_dp_record r;
+                r.x[0] = ent[i].x[0]; r.x[1] = ent[i].x[1]; r.x[2] = b; r.x[3] = 0;
+                r.d[0] = dd[0]; r.d[1] = dd[1];
+                r.kidx = type & 1;
+                r.reserved = 1;
+                recs.push_back(r);
+                if (recs.size() == C) flush();
+            }
+        }
+        flush();
+    }
+    if (running) release_workers(s);
+    out->seconds = seconds_since(t0);
+    s->audits++;
+    s->audited_kangaroos += out->kangaroos;
+    s->audit_mismatches += out->kangaroo_mismatches + out->table_mismatches;
     return rc;
 }
 

@@ -64,6 +64,8 @@ typedef struct kngs_stats {
     uint64_t herd_loaded;      /* kangaroos taken from the work file at start */
     uint64_t herd_created;     /* kangaroos created at start (none left in the file for them) */
     uint64_t table_bytes;      /* memory held by the table (0 while the consumers are running) */
+    uint64_t warmup_jumps;     /* part of `jumps`: the discarded warm-up launches of kngs_prepare (their DPs never reached the table) */
+    uint64_t audits, audited_kangaroos, audit_mismatches; /* kngs_audit, cumulative over this run */
 } kngs_stats;
 
 typedef struct kngs_solver kngs_solver;
@@ -88,6 +90,21 @@ int kngs_get_stats(const kngs_solver *s, kngs_stats *st);
 /* save a HEADW work file at the next launch boundary (GPUs pause, resume afterwards); with_kangaroos != 0
  * appends every herd (96 B per kangaroo, GPU order) like -ws.  Works while running and after kngs_stop. */
 int kngs_save(kngs_solver *s, const char *path, int with_kangaroos);
+/* Whole-run audit on the device (new; the reference's nearest tool is -wcheck on a saved file, Check.cpp:141-411, and the
+ * final key check, Kangaroo.cpp:196-206): every kangaroo of every herd is re-derived from its distance as d*G resp.
+ * K + d*G and compared in x and y (kng_audit_herd); with_table != 0 does the same for every entry of the table (what an
+ * entry keeps of x: 128 bits + the 18 bucket bits).  A walk error is permanent for its kangaroo, so a clean audit after
+ * J jumps certifies all J.  Works while running (the GPUs pause at a launch boundary, as for a save) and after the run
+ * has ended or was stopped.  Returns 0 when the audit RAN (look at the mismatch counts), <0 on error. */
+typedef struct kngs_audit_result {
+    uint64_t kangaroos, kangaroo_mismatches; /* herd half: all GPUs */
+    uint64_t table_points, table_mismatches; /* table half */
+    double herd_ms, table_ms;                /* device kernel time */
+    double seconds;                          /* wall time of the call, pause included */
+    uint32_t n_first_bad, reserved;
+    uint64_t first_bad[8];                   /* gpu << 56 | kIdx of the first mismatching kangaroos */
+} kngs_audit_result;
+int kngs_audit(kngs_solver *s, int with_table, kngs_audit_result *out);
 /* Kangaroo::CollisionCheck + CheckKey (Kangaroo.cpp:233-329) as a pure function of the configuration: given the
  * true distances (mod n) of a tame and a wild kangaroo standing on the same point, try the reference's four sign
  * combinations and return the private key (1) or 0 when none reproduces the public key.  No GPU needed. */

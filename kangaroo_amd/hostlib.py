@@ -122,6 +122,21 @@ def herd_params(range_power: int, key_xy=None, seed: int = 1):
     return table, windows, bt, bw, fin, wild_offset
 
 
+def audit_params(key_xy, wild_offset: int, seed: int = 0xA0D17):
+    """Inputs of kng_audit_setup: the full 16-window table and the offset points for a key whose wild herd was built
+    with `wild_offset` (kngh_herd_params at 128 bits, but with the caller's offset instead of 2^127)."""
+    table = np.zeros(16 * 256 * 8, np.uint64)
+    bt, bw, fin = np.zeros(8, np.uint64), np.zeros(8, np.uint64), np.zeros(8, np.uint64)
+    if key_xy is None:
+        kx = ky = None
+    else:
+        kxa, kya = limbs(key_xy[0]), limbs(key_xy[1])
+        kx, ky = kxa.ctypes.data, kya.ctypes.data
+    if load().kngh_herd_params(128, limbs(wild_offset), kx, ky, seed & _M64, table, bt, bw, fin) != 0:
+        raise RuntimeError("kngh_herd_params failed")
+    return table, 16, bt, bw, fin
+
+
 def to_device_distances(d_true: np.ndarray, wild_offset: int) -> np.ndarray:
     out = np.zeros((d_true.shape[0], 2), np.uint64)
     if load().kngh_to_device_distances(np.ascontiguousarray(d_true), d_true.shape[0], limbs(wild_offset), out) != 0:

@@ -45,7 +45,15 @@ class _Stats(C.Structure):
                 ("same_herd", C.c_uint64), ("wrong_collisions", C.c_uint64), ("table_items", C.c_uint64),
                 ("kangaroos", C.c_uint64), ("seconds", C.c_double), ("kernel_ms_avg", C.c_double), ("dp", C.c_int32),
                 ("range_power", C.c_int32), ("solved", C.c_int32), ("running", C.c_int32), ("seed", C.c_uint64),
-                ("herd_loaded", C.c_uint64), ("herd_created", C.c_uint64), ("table_bytes", C.c_uint64)]
+                ("herd_loaded", C.c_uint64), ("herd_created", C.c_uint64), ("table_bytes", C.c_uint64),
+                ("warmup_jumps", C.c_uint64), ("audits", C.c_uint64), ("audited_kangaroos", C.c_uint64),
+                ("audit_mismatches", C.c_uint64)]
+
+
+class _AuditResult(C.Structure):
+    _fields_ = [("kangaroos", C.c_uint64), ("kangaroo_mismatches", C.c_uint64), ("table_points", C.c_uint64),
+                ("table_mismatches", C.c_uint64), ("herd_ms", C.c_double), ("table_ms", C.c_double), ("seconds", C.c_double),
+                ("n_first_bad", C.c_uint32), ("reserved", C.c_uint32), ("first_bad", C.c_uint64 * 8)]
 
 
 DP_RECORD_DTYPE = np.dtype([("x", np.uint64, (4,)), ("d", np.uint64, (2,)), ("kidx", np.uint64), ("reserved", np.uint64)])
@@ -91,6 +99,7 @@ def _lib() -> C.CDLL:
         L.kngs_result.argtypes = [C.c_void_p, _U64P]
         L.kngs_get_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
         L.kngs_save.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.kngs_audit.argtypes = [C.c_void_p, C.c_int, C.POINTER(_AuditResult)]
         L.kngs_collision_key.argtypes = [C.c_void_p, _U64P, _U64P, _U64P]
         L.kngs_last_error.restype = C.c_char_p
         L.kngs_gpu_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -312,3 +321,12 @@ class Solver:
 
     def save(self, path: str, with_kangaroos: bool = True):
         self._check(self._L.kngs_save(self._h, path.encode(), 1 if with_kangaroos else 0))
+
+    def audit(self, with_table: bool = True) -> dict:
+        """Whole-run audit on the device (kngs_audit): every kangaroo of every herd -- and every table entry -- re-derived
+        from its distance.  Returns the counts; a clean run has kangaroo_mismatches == table_mismatches == 0."""
+        r = _AuditResult()
+        self._check(self._L.kngs_audit(self._h, 1 if with_table else 0, C.byref(r)))
+        out = {k: getattr(r, k) for k, _ in _AuditResult._fields_ if k not in ("first_bad", "reserved", "n_first_bad")}
+        out["first_bad"] = [(int(v) >> 56, int(v) & ((1 << 56) - 1)) for v in list(r.first_bad)[: r.n_first_bad]]
+        return out

@@ -124,3 +124,28 @@ def fold_rare_vectors(rng: np.random.Generator):
         consider((((_M32 - 976) << 224) | (h6 << 192) | (rnd() & ((1 << 192) - 1))) + 1, full)
     return out, found, want
 
+
+def ref_binary(name: str) -> str:
+    """Path of oracle/_ref/<name> (the reference program built from /root/reference by oracle/Makefile; the binaries travel
+    to the GPU box with the tree).  Missing: a box WITH a device fails -- there the reference-program rows (a14, g) must be
+    tested, not skipped -- a box without one skips.  KNG_REQUIRE_REF=1/0 overrides the detection."""
+    import os
+
+    import pytest
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", name)
+    if os.path.exists(exe):
+        return exe
+    need = os.environ.get("KNG_REQUIRE_REF")
+    if need is None:
+        try:
+            import kangaroo_amd
+
+            need = "1" if kangaroo_amd.device_count() > 0 else "0"
+        except Exception:
+            need = "0"
+    msg = f"oracle/_ref/{name} not built (python -c 'import __graft_entry__ as g; g.build()' where /root/reference exists)"
+    if need == "1":
+        pytest.fail(msg + ": on a box with a device the reference-program tests must run, not skip")
+    pytest.skip(msg)

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import (M128, N_ORDER, P, array_to_ints, device_distances, dp_multiset, ints_to_array, walk_fixture)
+from helpers import (M128, N_ORDER, P, array_to_ints, device_distances, dp_multiset, ints_to_array, ref_binary, walk_fixture)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -331,11 +331,11 @@ def test_full_size_herd_properties(kng, orc):
 
 
 @pytest.mark.parametrize("use_asm", [1, 0])
-@pytest.mark.parametrize("share", [1, 8])
+@pytest.mark.parametrize("share", [8])
 @pytest.mark.parametrize("rp", [72, 109, 125])
 def test_every_walk_kernel_vs_oracle(kng, orc, share, rp, use_asm):
-    """All eight instantiations of the walk kernel -- share 1/8 x {low-word distance streaming, both words} x {scheduled
-    asm loop, compiler-scheduled loop} -- as the engine itself selects them: a 72-bit range streams only the low word;
+    """All four instantiations of the walk kernel -- {low-word distance streaming, both words} x {scheduled asm loop,
+    compiler-scheduled loop}; round 4 dropped the share = 1 family -- as the engine itself selects them: a 72-bit range streams only the low word;
     BASELINE configs[3]'s 109-bit range (jump distances around 2^54: a lane's low word carries every ~700 jumps) still
     does with the scheduled loop, which adds the carries in the loop with L2 atomics, and streams both words with the
     compiler loop; configs[4]'s 125-bit range streams both.  States and the exact DP multiset over two launches."""
@@ -491,9 +491,7 @@ def test_reference_gpu_check_harness_on_our_engine():
     -g 8,128 keeps the herd below Check's hard-coded maxFound (65536 DPs at dp=8, Check.cpp:418,492)."""
     import subprocess
 
-    exe = os.path.join(ROOT, "oracle", "_ref", "kangaroo_hip")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/kangaroo_hip not built (needs /root/reference at build time)")
+    exe = ref_binary("kangaroo_hip")
     out = subprocess.run([exe, "-gpu", "-g", "8,128", "-check"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "CPU/GPU ok" in out.stdout, out.stdout[-2500:] + out.stderr[-500:]
     assert "DP found" in out.stdout and "warning" not in out.stdout.lower()
@@ -560,9 +558,7 @@ def test_reference_program_solves_in_txt_on_our_engine(tmp_path):
     GPUEngine) solving its own shipped known-answer input on the MI355X."""
     import subprocess
 
-    exe = os.path.join(ROOT, "oracle", "_ref", "kangaroo_hip")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/kangaroo_hip not built (needs /root/reference at build time)")
+    exe = ref_binary("kangaroo_hip")
     cfg = tmp_path / "in.txt"
     cfg.write_text("0\n%X\n%s\n" % (IN_TXT_RANGE_END, IN_TXT_PUBKEY))
     out = subprocess.run([exe, "-t", "0", "-gpu", "-g", "16,128", str(cfg)], capture_output=True, text=True, timeout=300)
@@ -576,9 +572,7 @@ def test_reference_program_drives_two_engines_concurrently(tmp_path):
     (every entry point selects its own device, nothing is global)."""
     import subprocess
 
-    exe = os.path.join(ROOT, "oracle", "_ref", "kangaroo_hip")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/kangaroo_hip not built (needs /root/reference at build time)")
+    exe = ref_binary("kangaroo_hip")
     cfg = tmp_path / "in.txt"
     cfg.write_text("0\n%X\n%s\n" % (IN_TXT_RANGE_END, IN_TXT_PUBKEY))
     out = subprocess.run([exe, "-t", "0", "-gpu", "-gpuId", "0,0", "-g", "32,128,32,128", str(cfg)], capture_output=True, text=True, timeout=300)
@@ -591,9 +585,7 @@ def test_reference_program_solves_64bit_range_on_our_engine(tmp_path):
     answer README.md:194-195) solved by the unmodified reference program on our engine."""
     import subprocess
 
-    exe = os.path.join(ROOT, "oracle", "_ref", "kangaroo_hip")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/kangaroo_hip not built (needs /root/reference at build time)")
+    exe = ref_binary("kangaroo_hip")
     cfg = tmp_path / "in64.txt"
     cfg.write_text("5B3F38AF935A3640D158E871CE6E9666DB862636383386EE0000000000000000\n"
                    "5B3F38AF935A3640D158E871CE6E9666DB862636383386EEFFFFFFFFFFFFFFFF\n"
@@ -638,9 +630,7 @@ def test_reference_workfile_roundtrip_125bit_on_our_engine(tmp_path, orc):
     import re
     import subprocess
 
-    exe = os.path.join(ROOT, "oracle", "_ref", "kangaroo_hip")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/kangaroo_hip not built (needs /root/reference at build time)")
+    exe = ref_binary("kangaroo_hip")
     cfg = tmp_path / "in125.txt"
     cfg.write_text("0\n1FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF\n%s\n" % IN_TXT_PUBKEY)
     f1, f2 = str(tmp_path / "a.work"), str(tmp_path / "b.work")
@@ -723,7 +713,7 @@ def test_ragged_groups_vs_oracle(kng, orc, grid, lanes):
     eng.close()
 
 
-@pytest.mark.parametrize("share", [1, 8])
+@pytest.mark.parametrize("share", [8])
 def test_distance_low_word_streaming_vs_oracle(kng, orc, share):
     """Option "dsplit": only the low word of the 128-bit distance streams through HBM; the high word is
     read-modified-written when the add carries and fetched when a DP is emitted.  Forced on with jump distances
@@ -759,7 +749,7 @@ def test_distance_low_word_streaming_vs_oracle(kng, orc, share):
     eng.close()
 
 
-@pytest.mark.parametrize("share,dsplit", [(8, 1), (8, 0), (1, 1)])
+@pytest.mark.parametrize("share,dsplit", [(8, 1), (8, 0)])
 def test_exact_path_exits_of_the_scheduled_loop(kng, orc, share, dsplit):
     """The scheduled asm loop leaves an iteration to the general arithmetic (walk_core) when its short forms may not be
     exact; since round 3 it decides that from a SUPERSET of the conditions (a word below 1024 in a difference, a word within

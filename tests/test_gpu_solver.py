@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from tests.helpers import N_ORDER, P
+from tests.helpers import N_ORDER, P, ref_binary
 
 pytestmark = pytest.mark.gpu
 
@@ -107,7 +107,7 @@ def test_save_restore_continue_and_reference_reads_it(sv, orc, tmp_path, start, 
     assert n1 == n and h1["dp"] == 6 and h1["count"] == sa["jumps"] and h1["key"] == kxy
     assert t1.count() == sa["dps"] - sa["same_herd"] > 0
 
-    if os.path.exists(REF_CPU):
+    if ref_binary("kangaroo_cpu"):  # (fails on a box with a device when the binary is missing)
         info = subprocess.run([REF_CPU, "-winfo", f1], capture_output=True, text=True, timeout=120).stdout
         assert f"DP Count  : {t1.count()} " in info and f"Kangaroos : {n} " in info, info
         chk = subprocess.run([REF_CPU, "-t", "8", "-wcheck", f1], capture_output=True, text=True, timeout=300).stdout
@@ -144,8 +144,7 @@ def test_save_restore_continue_and_reference_reads_it(sv, orc, tmp_path, start, 
 
 def test_reference_program_resumes_from_our_workfile(sv, tmp_path):
     """`kangaroo -i ours.work` (reference host code on our engine): loads our table and herd and finishes the solve."""
-    if not os.path.exists(REF_HIP):
-        pytest.skip("oracle/_ref/kangaroo_hip not built (needs /root/reference at build time)")
+    ref_binary("kangaroo_hip")
     start, end, pub, answer = IN64
     grid = (64, 128)
     s = sv.Solver(start, end, _decompress(pub), grid=grid, seed=21, max_launches=3)
@@ -194,7 +193,7 @@ def test_saves_while_running_are_consistent_snapshots(sv, tmp_path):
     assert st["jumps"] >= prev_count and st["wrong_collisions"] == 0 and st["dps_lost"] == 0
     assert st["table_items"] == st["dps"] - st["same_herd"]
     s.close()
-    if os.path.exists(REF_CPU):
+    if ref_binary("kangaroo_cpu"):  # (fails on a box with a device when the binary is missing)
         chk = subprocess.run([REF_CPU, "-t", "8", "-wcheck", path], capture_output=True, text=True, timeout=300).stdout
         assert "[100.000% OK]" in chk, chk[-1500:]
 
@@ -403,7 +402,7 @@ def test_configs4_save_restore_at_the_default_herd(sv, orc, tmp_path):
     lines.append(f"herd {gx}x{gy}x128 = {n} kangaroos, range 2^{rp}, dp {sa['dp']}: file {size / 1e6:.1f} MB (kangaroo section {96 * n / 1e6:.1f} MB)")
     lines.append(f"kngs_save  with kangaroos: {t_save:.3f} s = {size / t_save / 1e9:.2f} GB/s (device -> pinned staging -> file, atomic rename)")
 
-    if os.path.exists(REF_CPU):
+    if ref_binary("kangaroo_cpu"):  # (fails on a box with a device when the binary is missing)
         info = subprocess.run([REF_CPU, "-winfo", f1], capture_output=True, text=True, timeout=300).stdout
         assert f"Kangaroos : {n} " in info, info
         chk = subprocess.run([REF_CPU, "-t", "8", "-wcheck", f1], capture_output=True, text=True, timeout=600).stdout
