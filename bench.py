@@ -50,11 +50,35 @@ def log(msg):
     print(msg, file=sys.stderr, flush=True)
 
 
+def effective_cpus() -> float:
+    """CPUs this process may really use: hardware threads cut by the affinity mask and the cgroup CPU quota (the GPU boxes
+    show 256 hardware threads under a quota of 16 CPUs: threads beyond that only take turns)."""
+    n = float(os.cpu_count() or 1)
+    try:
+        n = min(n, float(len(os.sched_getaffinity(0))))
+    except Exception:
+        pass
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, float(q) / float(period))
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, q / period)
+        except Exception:
+            pass
+    return max(1.0, n)
+
+
 def cpu_baseline(seconds: float = 20.0) -> dict:
     """Reference SolveKeyCPU path on this host's cores (bounded sample)."""
     import kangaroo_amd.hostlib as hl
 
-    cores = os.cpu_count() or 1
+    hw = os.cpu_count() or 1
+    cores = max(1, int(effective_cpus() + 0.5))  # one thread per CPU the process may use (not per hardware thread it can see)
     ref = os.path.join(ROOT, "oracle", "_ref", "kangaroo_cpu")
     _, kx, ky = hl.pubkey(KEY)
     pub = ("02" if ky % 2 == 0 else "03") + f"{kx:064X}"
@@ -92,7 +116,7 @@ def cpu_baseline(seconds: float = 20.0) -> dict:
             steady.sort()
             return {"value": steady[len(steady) // 2], "unit": "MK/s", "cores": cores, "kind": "reference",
                     "sample": f"reference kangaroo -t {cores} on the same 80-bit input for {seconds:.0f} s, median of "
-                              f"{len(steady)} status samples"}
+                              f"{len(steady)} status samples; {hw} hardware threads visible, CPU quota of this process {effective_cpus():.1f}"}
     # fallback: the oracle's batched walk (single thread)
     import numpy as np
 
@@ -331,12 +355,21 @@ def bench_multi(args, ranks, n_gpus):
             per_gpu.append({"gpu": g, "device": devices[g], "launches": gs["launches"], "kernel_ms": round(kms, 3),
                             "kernel_rate": round(gs["kangaroos"] * k.KNG_NB_RUN / (kms * 1e-3) / 1e6, 1)})
         load = s.consumer_load()
+        host = s.host_stats()  # is the host keeping up?  (the threads are still alive: the kernel-side sums come after stop)
 
         class _Gpu0:  # the walk kernel that actually ran, from the engine of GPU 0 (every GPU gets the same options)
             get_option = staticmethod(lambda key: s.gpu_option(0, key))
 
         kernel, group = _kernel_name(_Gpu0), s.gpu_option(0, "group")
+        aud = None
+        try:  # whole-run audit on the devices, outside the clock: every kangaroo of every herd and every table entry
+            aud = s.audit(True)
+        except Exception as e:  # noqa: BLE001
+            aud = {"error": str(e)}
         s.stop()
+        after = s.host_stats()
+        for key in ("consumer_cpu_s", "consumer_runq_s", "consumer_busy_s", "consumer_nvcsw", "consumer_nivcsw"):
+            host[key] = after[key]
         s.close()
         assert all(p["launches"] == args.steps for p in per_gpu), per_gpu
         jumps = n_gpus * n * k.KNG_NB_RUN * args.steps
@@ -355,6 +388,11 @@ def bench_multi(args, ranks, n_gpus):
             },
             "per_gpu": per_gpu,
             "power": {"timed_region": power},  # per device: package power, GFX clock (rocm_smi index = HIP index assumed)
+            # the N-GPU line diagnoses itself: a host that cannot keep up shows here (late_launches > 0, host_ms_max above the
+            # kernel time, consumers near 100 % busy or waiting for CPUs) before it shows as value < kernel_rate_sum
+            "host": dict(host, points_per_s_offered=round(st["dps"] / elapsed / 1e6, 2), points_unit="M points/s",
+                         cpu_ns_per_point=round((host.get("consumer_cpu_s") or 0) / max(1, st["dps"]) * 1e9, 1)),
+            "audit": aud,
             "kernel_rate_sum": round(sum(p["kernel_rate"] for p in per_gpu), 1),
             "roofline": _roofline(kernel, kms, n, k.KNG_NB_RUN, group, note="per GPU, mean over GPUs"),
         }

@@ -43,7 +43,11 @@ struct Fine {
 // while memory is there.
 constexpr int MIN_CLASS = 0, MAX_CLASS = 48;
 constexpr size_t REGION_MIN = (size_t)64 << 10;       // an arena's first region; each further one doubles ...
-constexpr size_t REGION = (size_t)2 << 20;            // ... up to this (a small table must not cost N_ARENAS x 2 MiB)
+constexpr int REGION_DOUBLINGS = 12;                  // ... up to 256 MiB (a small table must not cost N_ARENAS x 2 MiB).
+// Large regions on purpose: address space is free (pages arrive on first touch), but every mmap takes the process's mm lock
+// for writing and has to wait for the page faults in flight on the neighbouring mapping it merges with -- huge-page faults
+// that clear 2 MiB each.  With 2 MiB regions the table threads of an 8-GPU run issued ~4000 mmaps per second and spent two
+// thirds of their time blocked behind one another (profiles/r04_dp_probe.txt: 16 consumers 138 M points/s, 32 consumers 117).
 constexpr unsigned ARENA_BITS = 6, N_ARENAS = 1u << ARENA_BITS;
 
 inline size_t class_bytes(int c) { return ((size_t)(c & 1 ? 96 : 64)) << (c >> 1); }
@@ -87,7 +91,7 @@ void *arena_alloc(Arena &a, int c) {
                 a.free_list[k] = a.cur;
                 a.cur += class_bytes(k);
             }
-        size_t want = REGION_MIN << (a.regions.size() < 5 ? a.regions.size() : 5);
+        size_t want = REGION_MIN << (a.regions.size() < (size_t)REGION_DOUBLINGS ? a.regions.size() : (size_t)REGION_DOUBLINGS);
         if (want < sz) want = sz;
         void *m = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (m == MAP_FAILED) return nullptr;
@@ -127,7 +131,12 @@ struct Bucket {
 
 constexpr uint64_t D_MASK = 0x3FFFFFFFFFFFFFFFULL;
 constexpr uint64_t D_SIGN = 1ULL << 63, D_TYPE = 1ULL << 62;
-constexpr uint32_t SPLIT_AVG = 32; // entries per fine array that trigger a re-split
+// entries per fine array that trigger a re-split into four times as many: runs then hold 2..8 entries (64..256 B).  Round 3 used
+// 32 (runs of 8..32): at 60-80 M entries an insertion cost 68-72 ns against 53-61 ns with 8, and 60 against 45 bytes of memory
+// per entry (less slack in short runs outweighs more 16-byte run headers); 16 table threads took 150 -> 182 M points/s
+// (profiles/r04_dp_probe_split.txt).  KNGT_SPLIT_AVG overrides it for measurements.
+static const uint32_t SPLIT_AVG = getenv("KNGT_SPLIT_AVG") ? (uint32_t)atoi(getenv("KNGT_SPLIT_AVG")) : 8;
+static const bool GROW2 = getenv("KNGT_GROW2") && atoi(getenv("KNGT_GROW2")); // runs grow by doubling instead of by size class (measurement knob)
 constexpr uint8_t K_MAX = 24;
 
 inline int cmp_x(const uint64_t a[2], const uint64_t b[2]) {
@@ -221,15 +230,22 @@ uint8_t k_for(uint32_t n) {
 } // namespace
 
 struct kngt_table {
+    // Bucket headers are stored in SCRAMBLED order, slot(h) = the bijection of the 18-bit bucket index that kng_solver's
+    // consumer_of() cuts into equal ranges: a consumer's buckets are then one contiguous stretch of this array (190 KB of
+    // 24-byte headers at 32 consumers: they live in its L2) instead of being interleaved line by line with every other
+    // consumer's.  Round 3 stored them in file order: each 64-byte line held headers of two or three different owners,
+    // every insertion wrote one (n, ref_max), and the lines bounced between cores and sockets -- consumers slowed from
+    // 75 ns per point alone to 130 / 240 / 370 ns at 16 / 32 / 64 threads (profiles/r04_dp_host_before.txt).
     Bucket b[KNGT_BUCKETS];
     Arena arena[N_ARENAS];
 };
 
 namespace {
-// the scramble kng_solver's consumer_of() uses: the buckets of an arena belong to one consumer, or to two neighbours
-inline Arena &arena_of(kngt_table *t, uint32_t h) {
-    return t->arena[(((h & (KNGT_BUCKETS - 1)) * 0x9E3779B1u) & (KNGT_BUCKETS - 1)) >> (KNGT_HASH_BITS - ARENA_BITS)];
-}
+inline uint32_t slot_of(uint32_t h) { return ((h & (KNGT_BUCKETS - 1)) * 0x9E3779B1u) & (KNGT_BUCKETS - 1); }
+inline Bucket &bucket_of(kngt_table *t, uint32_t h) { return t->b[slot_of(h)]; }
+inline const Bucket &bucket_of(const kngt_table *t, uint32_t h) { return t->b[slot_of(h)]; }
+// the arenas follow the same order: the buckets of an arena belong to one consumer, or to two neighbours
+inline Arena &arena_of(kngt_table *t, uint32_t h) { return t->arena[slot_of(h) >> (KNGT_HASH_BITS - ARENA_BITS)]; }
 } // namespace
 
 extern "C" {
@@ -301,7 +317,7 @@ void kngt_decode(const uint64_t d_word[2], uint64_t d_true[4], uint32_t *type) {
 }
 
 void kngt_prefetch(const kngt_table *t, uint32_t h, uint64_t x1, int stage) {
-    const Bucket &b = t->b[h & (KNGT_BUCKETS - 1)];
+    const Bucket &b = bucket_of(t, h);
     if (stage == 0) {
         __builtin_prefetch(&b);
     } else if (b.fine) {
@@ -309,14 +325,15 @@ void kngt_prefetch(const kngt_table *t, uint32_t h, uint64_t x1, int stage) {
         if (stage == 1) {
             __builtin_prefetch(f);
         } else if (f->e) { // the whole run: the search reads a few of its lines, the insertion shifts the rest
+            static const int lines = getenv("KNGT_PF_LINES") ? atoi(getenv("KNGT_PF_LINES")) : 12; // (measurement knob)
             const char *p = reinterpret_cast<const char *>(f->e), *end = p + (size_t)(f->n + 1) * sizeof(kngt_entry);
-            for (int i = 0; i < 12 && p < end; i++, p += 64) __builtin_prefetch(p, 1);
+            for (int i = 0; i < lines && p < end; i++, p += 64) __builtin_prefetch(p, 1);
         }
     }
 }
 
 int kngt_add_entry(kngt_table *t, uint32_t h, const kngt_entry *e, kngt_entry *other) {
-    Bucket &b = t->b[h & (KNGT_BUCKETS - 1)];
+    Bucket &b = bucket_of(t, h);
     // the reference's allocation bookkeeping, reproduced for the file format: first use -> 16, and a
     // +4 step whenever the bucket is within one slot of full at the START of an add (even one that
     // ends as DUPLICATE/COLLISION)
@@ -338,7 +355,7 @@ int kngt_add_entry(kngt_table *t, uint32_t h, const kngt_entry *e, kngt_entry *o
         return KNGT_ADD_COLLISION;
     }
     if (b.n == 0xFFFFFFFFu) return -1; // nbItem is a 32-bit word of the file format
-    if (!reserve(ar, f, f.n + 1)) return -1;
+    if (!reserve(ar, f, (GROW2 && f.n + 1 > f.cap && f.cap >= 4) ? 2 * f.cap : f.n + 1)) return -1;
     std::memmove(f.e + lo + 1, f.e + lo, (size_t)(f.n - lo) * sizeof(kngt_entry));
     f.e[lo] = *e;
     f.n++;
@@ -369,10 +386,10 @@ uint64_t kngt_count(const kngt_table *t) {
     return c;
 }
 
-uint32_t kngt_bucket_count(const kngt_table *t, uint32_t bucket) { return t->b[bucket & (KNGT_BUCKETS - 1)].n; }
+uint32_t kngt_bucket_count(const kngt_table *t, uint32_t bucket) { return bucket_of(t, bucket).n; }
 
 uint32_t kngt_bucket_entries(const kngt_table *t, uint32_t bucket, kngt_entry *out, uint32_t cap) {
-    const Bucket &b = t->b[bucket & (KNGT_BUCKETS - 1)];
+    const Bucket &b = bucket_of(t, bucket);
     if (b.n <= cap) {
         gather(b, out);
         return b.n;
@@ -387,12 +404,13 @@ uint64_t kngt_serialised_size(const kngt_table *t) { return (uint64_t)KNGT_BUCKE
 
 uint64_t kngt_memory_bytes(const kngt_table *t) {
     uint64_t m = sizeof(kngt_table);
-    for (const Arena &a : t->arena) m += a.bytes;
+    for (const Arena &a : t->arena) m += a.bytes - (uint64_t)(a.end - a.cur); // mapped less the untouched tail of the current region
     return m;
 }
 
 int kngt_write(const kngt_table *t, FILE *f) {
-    for (const Bucket &b : t->b) {
+    for (uint32_t h = 0; h < KNGT_BUCKETS; h++) { // file order = bucket index order (HashTable.cpp:375-396)
+        const Bucket &b = bucket_of(t, h);
         const uint32_t head[2] = {b.n, b.ref_max};
         if (std::fwrite(head, 4, 2, f) != 2) return -1;
         if (!b.fine) continue;
@@ -412,7 +430,8 @@ static int read_buckets(kngt_table *t, FILE *f) {
     if (pos >= 0 && fstat(fileno(f), &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size >= (uint64_t)pos)
         remaining = (uint64_t)sb.st_size - (uint64_t)pos;
     std::vector<kngt_entry> buf;
-    for (Bucket &b : t->b) {
+    for (uint32_t h = 0; h < KNGT_BUCKETS; h++) {
+        Bucket &b = bucket_of(t, h);
         uint32_t head[2];
         if (std::fread(head, 4, 2, f) != 2) return -1;
         if (remaining != UINT64_MAX) remaining -= remaining < 8 ? remaining : 8;
@@ -426,7 +445,7 @@ static int read_buckets(kngt_table *t, FILE *f) {
         // Add() binary-searches the bucket: it must be strictly ascending in (x.limb1, x.limb0) as the reference writes it
         for (uint32_t i = 1; i < n; i++)
             if (cmp_x(buf[i - 1].x, buf[i].x) >= 0) return -1;
-        if (!build(arena_of(t, (uint32_t)(&b - t->b)), b, k_for(n), buf.data(), n)) return -1;
+        if (!build(arena_of(t, h), b, k_for(n), buf.data(), n)) return -1;
         b.n = n;
     }
     return 0;

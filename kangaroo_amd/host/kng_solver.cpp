@@ -1,6 +1,13 @@
 // kng_solver.cpp -- see kng_solver.h.  Product code: host pipeline over the C ABI of the engine.
 #include "kng_solver.h"
 
+#include <sched.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+#include <sys/mman.h>
+#include <sys/resource.h>
+
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -65,6 +72,8 @@ int bit_length(const U256 &a) {
 const uint64_t P_FIELD[4] = {0xFFFFFFFEFFFFFC2FULL, ~0ULL, ~0ULL, ~0ULL};
 const uint64_t ZERO4[4] = {0, 0, 0, 0};
 
+constexpr uint64_t INFLIGHT_LIMIT = 96ull << 20; // points queued for the table (x 48 B = 4.8 GB) beyond which GPU threads wait
+
 // one distinguished point on its way to the table
 struct DpMsg {
     kngt_entry e;
@@ -73,12 +82,87 @@ struct DpMsg {
     uint64_t kidx;
 };
 
+// Messages travel in fixed-size chunks that come from -- and go back to -- a pool which only ever grows (slabs of huge pages,
+// released when the solver is destroyed).  Round 3 moved one std::vector per consumer and launch and let the heap recycle them:
+// at the 8-GPU rate that is ~6 GB/s of 4 KiB page faults on the GPU threads and, whenever the consumers fall behind and the
+// vectors pile up, munmap + TLB shootdowns across all 40 threads -- the whole path stalled at ~100 M points/s whatever the
+// number of consumers (profiles/r04_dp_host_before.txt).  In steady state a chunk now costs two short critical sections.
+constexpr uint32_t CHUNK_MSGS = 2044; // 64-byte header + 2044 x 48 B: just under 96 KiB; a multiple of the staging group (ingest)
+struct alignas(64) Chunk {
+    Chunk *next;
+    uint32_t n, pad;
+    alignas(64) DpMsg m[CHUNK_MSGS];
+};
+static_assert(sizeof(DpMsg) == 48 && sizeof(Chunk) <= 96 * 1024, "64 chunks fit three huge pages");
+struct ChunkPool {
+    std::mutex m;
+    Chunk *free_list = nullptr;
+    std::vector<std::pair<void *, size_t>> slabs;
+    uint64_t made = 0;
+    Chunk *get() {
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (Chunk *c = free_list) {
+                free_list = c->next;
+                c->n = 0;
+                return c;
+            }
+        }
+        // a new slab: 64 chunks = 6 MiB, mapped outside the lock (several GPU threads may grow the pool at once)
+        const size_t per = 64, bytes = (per * sizeof(Chunk) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        void *mem = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (mem == MAP_FAILED) return nullptr;
+        (void)madvise(mem, bytes, MADV_HUGEPAGE);
+        Chunk *c = static_cast<Chunk *>(mem);
+        std::lock_guard<std::mutex> g(m);
+        slabs.emplace_back(mem, bytes);
+        made += per;
+        for (size_t i = 1; i < per; i++) {
+            c[i].next = free_list;
+            free_list = &c[i];
+        }
+        c[0].n = 0;
+        return &c[0];
+    }
+    void put(Chunk *c) {
+        std::lock_guard<std::mutex> g(m);
+        c->next = free_list;
+        free_list = c;
+    }
+    ~ChunkPool() {
+        for (auto &sl : slabs) munmap(sl.first, sl.second);
+    }
+};
+
+// whole cache lines, written around the caches (dst 64-byte aligned, bytes a multiple of 16)
+inline void stream_copy(void *dst, const void *src, size_t bytes) {
+#if defined(__SSE2__)
+    __m128i *d = static_cast<__m128i *>(dst);
+    const __m128i *sp = static_cast<const __m128i *>(src);
+    for (size_t i = 0; i < bytes / 16; i++) _mm_stream_si128(d + i, _mm_loadu_si128(sp + i));
+#else
+    std::memcpy(dst, src, bytes);
+#endif
+}
+inline void stream_fence() {
+#if defined(__SSE2__)
+    _mm_sfence();
+#endif
+}
+
 struct Consumer {
     std::mutex m;
     std::condition_variable cv;
-    std::deque<std::vector<DpMsg>> q;
+    std::deque<Chunk *> q;
     std::thread th;
     std::atomic<uint64_t> handled{0}; // points taken off the queue (load balance across consumers)
+    std::atomic<uint64_t> busy_ns{0}; // time spent inserting (the rest of the run it slept on its queue)
+    // the kernel's view of the thread, read when it ends: on-CPU time, time runnable but waiting for a CPU, context switches
+    std::atomic<uint64_t> cpu_ns{0}, runq_ns{0}, nvcsw{0}, nivcsw{0};
+    bool pin = false;                 // confine the thread to one NUMA node's CPUs (start_consumers)
+    cpu_set_t cpus;
+    uint64_t queued = 0;              // points waiting in q (under m)
+    std::atomic<uint64_t> queued_high{0};
 };
 
 struct Worker {
@@ -90,9 +174,14 @@ struct Worker {
     std::vector<uint64_t> resets; // kangaroos to replace (same-herd collisions), filled by the consumers
     std::atomic<uint64_t> launches{0};
     std::atomic<uint64_t> kernel_us_sum{0}; // walk-kernel time of all launches, microseconds
+    // host work between two kng_wait calls (launch, drain, ingest, replacements): while it stays below the kernel time the
+    // GPU never waits for its host thread.  `late` counts the launches where it did not.
+    std::atomic<uint64_t> host_us_sum{0}, host_us_max{0}, ingest_us_max{0}, late{0};
     bool ended = false, paused = false; // guarded by kngs_solver::ctl_m
     uint64_t reset_seq = 0;
-    std::vector<std::vector<DpMsg>> out; // per-consumer batches being filled by ingest()
+    std::vector<Chunk *> out; // per-consumer chunk being filled by ingest()
+    std::vector<DpMsg> stage;    // per-consumer staging groups of ingest() (software write-combining)
+    std::vector<uint8_t> staged; // messages waiting in each group
 };
 
 } // namespace
@@ -110,8 +199,7 @@ struct kngs_solver {
     std::vector<Worker *> workers;
     std::vector<Consumer *> consumers;
     std::atomic<uint64_t> inflight{0}; // DP messages queued but not yet in the table
-    std::mutex pool_m;
-    std::vector<std::vector<DpMsg>> pool; // emptied batch buffers on their way back to the GPU threads
+    ChunkPool pool; // message chunks: GPU threads take, consumers return
 
     // control
     std::mutex ctl_m;
@@ -138,6 +226,8 @@ struct kngs_solver {
     uint64_t herd_loaded = 0, herd_created = 0;
     uint64_t audits = 0, audited_kangaroos = 0, audit_mismatches = 0; // kngs_audit, cumulative
     uint64_t seed_used = 0;
+    int numa_nodes = 0;       // nodes the consumers were spread over (0/1 = not pinned)
+    double cpus = 0;          // CPUs the process may use (affinity, cgroup quota)
     bool prepared = false;    // engines created, herds in place (kngs_prepare)
     bool ingest_only = false; // kngs_start_ingest: consumers without engines (host-path measurements)
 };
@@ -177,18 +267,97 @@ void request_reset(kngs_solver *s, const DpMsg &m) {
     w->resets.push_back(m.kidx);
 }
 
+// ---- NUMA placement of the table threads.  The table grows by gigabytes per second and every insertion is a handful of
+// dependent cache misses: a consumer that wanders between sockets (or whose arenas were first touched on the other one)
+// pays the remote latency on each of them.  Consumer i of n is confined to the CPUs of node i * nodes / n, so that the
+// memory its arenas take from the OS (first touch) stays local for the whole run.  No libnuma: sysfs + sched_setaffinity.
+std::vector<cpu_set_t> numa_node_cpus() {
+    std::vector<cpu_set_t> nodes;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return nodes;
+    for (int node = 0; node < 64; node++) {
+        char path[96];
+        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+        FILE *f = fopen(path, "r");
+        if (!f) break;
+        char buf[4096];
+        const bool ok = fgets(buf, sizeof buf, f) != nullptr;
+        fclose(f);
+        if (!ok) break;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        int n_set = 0;
+        for (char *p = buf; *p;) { // "0-63,128-191"
+            char *e;
+            const long a = strtol(p, &e, 10);
+            if (e == p) break;
+            long b = a;
+            p = e;
+            if (*p == '-') b = strtol(p + 1, &p, 10);
+            for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+                if (CPU_ISSET((int)c, &allowed)) {
+                    CPU_SET((int)c, &set);
+                    n_set++;
+                }
+            if (*p == ',') p++;
+        }
+        if (n_set) nodes.push_back(set);
+    }
+    return nodes;
+}
+
+// one logical CPU per physical core of `set`: the lowest-numbered hardware thread of each core
+std::vector<int> primary_cpus(const cpu_set_t &set) {
+    std::vector<int> out;
+    for (int cpu = 0; cpu < CPU_SETSIZE; cpu++) {
+        if (!CPU_ISSET(cpu, &set)) continue;
+        char path[128];
+        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
+        int first = cpu;
+        if (FILE *f = fopen(path, "r")) {
+            if (fscanf(f, "%d", &first) != 1) first = cpu;
+            fclose(f);
+        }
+        if (first == cpu || !CPU_ISSET(first, &set)) out.push_back(cpu);
+    }
+    return out;
+}
+
 void consumer_main(kngs_solver *s, Consumer *c) {
+    if (c->pin) (void)sched_setaffinity(0, sizeof c->cpus, &c->cpus); // (0 = the calling thread)
+    struct AtExit {
+        Consumer *c;
+        ~AtExit() {
+            if (FILE *f = fopen("/proc/thread-self/schedstat", "r")) {
+                unsigned long long cpu = 0, runq = 0;
+                if (fscanf(f, "%llu %llu", &cpu, &runq) == 2) {
+                    c->cpu_ns = cpu;
+                    c->runq_ns = runq;
+                }
+                fclose(f);
+            }
+            struct rusage ru;
+            if (getrusage(RUSAGE_THREAD, &ru) == 0) {
+                c->nvcsw = (uint64_t)ru.ru_nvcsw;
+                c->nivcsw = (uint64_t)ru.ru_nivcsw;
+            }
+        }
+    } at_exit{c};
     for (;;) {
-        std::vector<DpMsg> batch;
+        Chunk *chunk;
         {
             std::unique_lock<std::mutex> lk(c->m);
             c->cv.wait(lk, [&] { return !c->q.empty() || s->consumers_quit.load(); });
             if (c->q.empty()) return;
-            batch.swap(c->q.front());
+            chunk = c->q.front();
             c->q.pop_front();
+            c->queued -= chunk->n;
         }
-        c->handled += batch.size();
-        const size_t nb = batch.size();
+        const auto busy0 = Clock::now();
+        const DpMsg *batch = chunk->m;
+        const size_t nb = chunk->n;
+        c->handled += nb;
         for (size_t bi = 0; bi < nb; bi++) {
             // the table is far larger than the caches: touch bucket header, run header and run a few points ahead
             if (bi + 12 < nb) kngt_prefetch(s->table, batch[bi + 12].bucket, batch[bi + 12].e.x[1], 0);
@@ -231,10 +400,9 @@ void consumer_main(kngs_solver *s, Consumer *c) {
                 request_reset(s, m);
             }
         }
-        s->inflight -= batch.size();
-        batch.clear();
-        std::lock_guard<std::mutex> g(s->pool_m);
-        if (s->pool.size() < 4 * s->consumers.size() * (s->workers.size() + 1)) s->pool.emplace_back(std::move(batch));
+        s->inflight -= nb;
+        s->pool.put(chunk);
+        c->busy_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - busy0).count();
     }
 }
 
@@ -262,42 +430,91 @@ inline size_t consumer_of(uint32_t bucket, size_t nc) {
 }
 
 void ingest(kngs_solver *s, Worker *w, const kng_dp_record *rec, uint32_t n) {
-    const size_t nc = s->consumers.size();
-    if (w->out.size() != nc) w->out.resize(nc);
-    const size_t want = n / nc + n / (4 * nc) + 64; // a consumer's share, with room for the spread
-    for (size_t c = 0; c < nc; c++) {
-        std::vector<DpMsg> &v = w->out[c];
-        if (v.capacity() < want) {
-            std::vector<DpMsg> spare;
-            {
-                std::lock_guard<std::mutex> g(s->pool_m);
-                if (!s->pool.empty()) {
-                    spare.swap(s->pool.back());
-                    s->pool.pop_back();
-                }
-            }
-            if (spare.capacity() > v.capacity()) v.swap(spare);
-            v.clear();
-            v.reserve(want);
+    struct Timed { // every exit path
+        Worker *w;
+        Clock::time_point t0 = Clock::now();
+        ~Timed() {
+            const uint64_t us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - t0).count();
+            if (us > w->ingest_us_max.load(std::memory_order_relaxed)) w->ingest_us_max.store(us, std::memory_order_relaxed);
         }
-    }
-    for (uint32_t i = 0; i < n; i++) {
-        DpMsg m;
-        kngt_encode_device(rec[i].x, rec[i].d, s->wild_offset.v, rec[i].kidx, &m.bucket, &m.e);
-        m.gpu = (uint32_t)w->index;
-        m.kidx = rec[i].kidx;
-        w->out[consumer_of(m.bucket, nc)].push_back(m);
-    }
-    for (size_t c = 0; c < nc; c++) {
-        if (w->out[c].empty()) continue;
-        s->inflight += w->out[c].size();
+    } timed{w};
+    const size_t nc = s->consumers.size();
+    if (w->out.size() != nc) w->out.assign(nc, nullptr);
+    // back-pressure instead of unbounded memory: a host whose table threads cannot keep up makes its GPU threads wait here
+    // (and shows it: late_launches, queue_high_points), it does not pile up gigabytes of messages
+    while (s->inflight.load(std::memory_order_relaxed) > INFLIGHT_LIMIT && !s->stop && !s->failed) std::this_thread::sleep_for(std::chrono::microseconds(200));
+    auto hand_over = [&](size_t c) {
+        Chunk *ch = w->out[c];
+        w->out[c] = nullptr;
+        s->inflight += ch->n;
         Consumer *cs = s->consumers[c];
+        bool wake;
         {
             std::lock_guard<std::mutex> g(cs->m);
-            cs->q.emplace_back(std::move(w->out[c]));
+            cs->queued += ch->n;
+            if (cs->queued > cs->queued_high.load(std::memory_order_relaxed)) cs->queued_high.store(cs->queued, std::memory_order_relaxed);
+            wake = cs->q.empty();
+            cs->q.push_back(ch);
         }
-        cs->cv.notify_one();
-        w->out[c] = std::vector<DpMsg>();
+        if (wake) cs->cv.notify_one();
+    };
+    // Software write-combining (the radix-partitioning idiom): a point's message first goes to a small per-consumer staging
+    // group in this thread's L1; a full group -- four messages = three whole cache lines -- is written to the consumer's chunk
+    // with streaming stores.  Without it every one of the nc output streams costs a read-for-ownership per line, of a line a
+    // consumer on another core (or socket) read last: the hand-over slowed from 26 to 59 ns per point between an idle table and
+    // 32 busy consumers, and the consumers then fetched every message line out of this core's cache
+    // (profiles/r04_dp_host_chunks.txt).  Streamed lines bypass the caches both ways.
+    constexpr uint32_t GROUP = 4;
+    static_assert(CHUNK_MSGS % GROUP == 0 && (GROUP * sizeof(DpMsg)) % 64 == 0, "a staging group is whole cache lines");
+    if (w->stage.size() != nc * GROUP) {
+        w->stage.assign(nc * GROUP, DpMsg());
+        w->staged.assign(nc, 0);
+    }
+    DpMsg *const stage = w->stage.data();
+    uint8_t *const staged = w->staged.data();
+    auto chunk_for = [&](size_t c) -> Chunk * {
+        Chunk *ch = w->out[c];
+        if (!ch) ch = w->out[c] = s->pool.get();
+        return ch;
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t bucket;
+        kngt_entry e;
+        kngt_encode_device(rec[i].x, rec[i].d, s->wild_offset.v, rec[i].kidx, &bucket, &e);
+        const size_t c = consumer_of(bucket, nc);
+        DpMsg &m = stage[c * GROUP + staged[c]];
+        m.e = e;
+        m.bucket = bucket;
+        m.gpu = (uint32_t)w->index;
+        m.kidx = rec[i].kidx;
+        if (++staged[c] < GROUP) continue;
+        staged[c] = 0;
+        Chunk *ch = chunk_for(c);
+        if (!ch) {
+            set_error(s, "out of memory for distinguished-point messages");
+            return;
+        }
+        stream_copy(&ch->m[ch->n], &stage[c * GROUP], GROUP * sizeof(DpMsg));
+        ch->n += GROUP;
+        if (ch->n == CHUNK_MSGS) {
+            stream_fence();
+            hand_over(c);
+        }
+    }
+    // the launch's points reach the table within the launch: the staged remainders and the partly filled chunks go too
+    stream_fence();
+    for (size_t c = 0; c < nc; c++) {
+        if (staged[c]) {
+            Chunk *ch = chunk_for(c);
+            if (!ch) {
+                set_error(s, "out of memory for distinguished-point messages");
+                return;
+            }
+            std::memcpy(&ch->m[ch->n], &stage[c * GROUP], staged[c] * sizeof(DpMsg)); // (n <= CHUNK_MSGS - GROUP here)
+            ch->n += staged[c];
+            staged[c] = 0;
+        }
+        if (w->out[c] && w->out[c]->n) hand_over(c);
     }
 }
 
@@ -310,10 +527,24 @@ void worker_main(kngs_solver *s, Worker *w) {
     };
 
     if (kng_launch(w->eng) != KNG_OK) return bail(std::string("kng_launch: ") + kng_last_error());
+    Clock::time_point host_t0{};
+    bool have_host_t0 = false;
     for (;;) {
+        if (have_host_t0) { // the host's share of the last cycle: everything between two kng_wait calls
+            const uint64_t us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - host_t0).count();
+            w->host_us_sum += us;
+            if (us > w->host_us_max.load(std::memory_order_relaxed)) w->host_us_max.store(us, std::memory_order_relaxed);
+        }
         if (kng_wait(w->eng, 0) != KNG_OK) return bail(std::string("kng_wait: ") + kng_last_error());
         float ms = 0;
         kng_last_kernel_ms(w->eng, &ms);
+        if (have_host_t0) {
+            const uint64_t us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - host_t0).count();
+            // the kernel this wait returned from was started at host_t0: a host cycle longer than it left the GPU idle
+            if ((double)us > (double)ms * 1000.0 * 1.10 + 500.0) w->late++;
+        }
+        host_t0 = Clock::now();
+        have_host_t0 = true;
         w->kernel_us_sum += (uint64_t)(ms * 1000.0f + 0.5f);
         const uint64_t done = ++w->launches;
         const bool last = s->cfg.max_launches && done >= s->cfg.max_launches;
@@ -499,9 +730,47 @@ int kngs_load(kngs_solver *s, const char *path) {
 
 namespace {
 
+double effective_cpus();
+
 // everything kngs_start and kngs_start_ingest share: consumers, clock, state
 void start_consumers(kngs_solver *s, int nc) {
     for (int c = 0; c < nc; c++) s->consumers.push_back(new Consumer());
+    const std::vector<cpu_set_t> nodes = (s->cfg.flags & KNGS_FLAG_NO_PIN) ? std::vector<cpu_set_t>() : numa_node_cpus();
+    if (nodes.size() > 1) {
+        // one physical core per consumer, spread evenly over the node's cores (hence over its L3 slices): left to itself the
+        // scheduler wakes a table thread next to the GPU thread that fed it, and a dozen of them end up sharing a few cores
+        // and one L3 while the rest of the socket idles (profiles/r04_dp_host_bigregions.txt: 16 threads 159 M points/s,
+        // 32 threads 107).  A node with fewer cores than consumers gets its whole CPU set instead.
+        const char *mode = getenv("KNGS_PIN");
+        const bool per_core = !mode || std::string(mode) != "node";
+        for (size_t nd = 0; nd < nodes.size(); nd++) {
+            std::vector<int> mine; // consumers of this node
+            for (int c = 0; c < nc; c++)
+                if ((size_t)c * nodes.size() / (size_t)nc == nd) mine.push_back(c);
+            std::vector<int> cores = per_core ? primary_cpus(nodes[nd]) : std::vector<int>();
+            for (size_t j = 0; j < mine.size(); j++) {
+                Consumer *cs = s->consumers[(size_t)mine[j]];
+                cs->pin = true;
+                if (cores.size() >= mine.size()) {
+                    CPU_ZERO(&cs->cpus);
+                    CPU_SET(cores[j * cores.size() / mine.size()], &cs->cpus);
+                } else {
+                    cs->cpus = nodes[nd];
+                }
+            }
+        }
+    }
+    s->numa_nodes = (int)nodes.size();
+    s->cpus = effective_cpus();
+    { // the first launch must not pay for the pool: one chunk per (GPU thread, consumer) pair, touched once
+        std::vector<Chunk *> warm;
+        for (size_t i = 0; i < (size_t)nc * (s->workers.size() + 1); i++)
+            if (Chunk *c = s->pool.get()) {
+                for (size_t off = 0; off < sizeof(Chunk); off += 4096) reinterpret_cast<volatile char *>(c)[off] = 0;
+                warm.push_back(c);
+            }
+        for (Chunk *c : warm) s->pool.put(c);
+    }
     s->t_start = Clock::now();
     s->started = true;
     for (Consumer *c : s->consumers) c->th = std::thread(consumer_main, s, c);
@@ -511,11 +780,50 @@ void start_consumers(kngs_solver *s, int nc) {
 // emits 1.3 M points/s at its own suggested DP size, eight GPUs 85 M/s at theirs (the suggestion shrinks with the
 // population, Kangaroo.cpp:980-993) -- which 16 threads absorb on the GPU box's host (profiles/r02_dp_ingest_arena.txt):
 // four threads per GPU, within half of the host's hardware threads
+// CPUs this process may actually use: hardware threads, cut by its affinity mask and by the cgroup's CPU quota.  (The GPU
+// boxes of this project show 256 hardware threads under a quota of 16 CPUs: threads beyond the quota do not run in parallel,
+// they take turns -- 32 table threads were SLOWER than 16 there, 8 s of their 27 s spent runnable but waiting for a CPU,
+// profiles/r04_dp_probe3.txt.)
+double effective_cpus() {
+    double n = (double)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < n) n = CPU_COUNT(&set);
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota|max> <period>"
+        char q[32];
+        double period = 0;
+        if (fscanf(f, "%31s %lf", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
+            const double c = atof(q) / period;
+            if (c > 0 && c < n) n = c;
+        }
+        fclose(f);
+    } else {
+        double quota = -1, period = 0;
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(g, "%lf", &quota) != 1) quota = -1;
+            fclose(g);
+        }
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(g, "%lf", &period) != 1) period = 0;
+            fclose(g);
+        }
+        if (quota > 0 && period > 0 && quota / period < n) n = quota / period;
+    }
+    return n < 1 ? 1 : n;
+}
+
+// A table thread inserts 11-14 M points per second of CPU time (75-90 ns each, tools/dp_table_bench); a GPU thread spends
+// 16-25 ns per point handing them over.  One GPU emits 1.5 M points/s at its own suggested DP size, eight GPUs 100 M/s at
+// theirs (the suggestion shrinks with the population, Kangaroo.cpp:980-993): four table threads per GPU give that 3-4x
+// headroom -- but never more threads than the process has CPUs, because surplus threads under a CPU quota only take turns
+// (the GPU threads need about a seventh of a CPU each; on the 16-CPU box 16 table threads absorbed 174 M points/s from
+// eight flat-out feeders, 14 threads 128 M, 32 threads the same 174 M with half their time spent waiting for a CPU:
+// profiles/r04_dp_host_after.txt).
 int default_consumers(int asked, int n_gpus) {
     if (asked > 0) return asked;
-    const int hw = (int)std::thread::hardware_concurrency();
     int nc = n_gpus == 1 ? 1 : 4 * n_gpus;
-    if (hw > 0 && nc > hw / 2) nc = hw / 2;
+    const int room = (int)(effective_cpus() + 0.5);
+    if (nc > room) nc = room;
     if (nc > 64) nc = 64;
     if (nc < 2 && n_gpus > 1) nc = 2;
     return nc < 1 ? 1 : nc;
@@ -702,6 +1010,39 @@ int kngs_gpu_option(const kngs_solver *s, int gpu, const char *key, int64_t *val
     const Worker *w = s->workers[(size_t)gpu];
     if (!w->eng) return fail("gpu %d has no engine yet (kngs_prepare)", gpu);
     if (kng_get_option(w->eng, key, value) != KNG_OK) return fail("%s", kng_last_error());
+    return 0;
+}
+
+int kngs_host_stats(const kngs_solver *s, kngs_host_stats_t *out) {
+    if (!s || !out) return fail("null argument");
+    std::memset(out, 0, sizeof *out);
+    const double run_s = s->started ? (s->joined ? s->run_seconds : seconds_since(s->t_start)) : 0.0;
+    out->consumers = (uint32_t)s->consumers.size();
+    double busy_sum = 0;
+    for (const Consumer *c : s->consumers) {
+        const double b = (double)c->busy_ns.load() * 1e-9;
+        busy_sum += b;
+        if (run_s > 0 && b / run_s > out->consumer_busy_max) out->consumer_busy_max = b / run_s;
+        out->consumer_cpu_s += (double)c->cpu_ns.load() * 1e-9;
+        out->consumer_runq_s += (double)c->runq_ns.load() * 1e-9;
+        out->consumer_busy_s += b;
+        out->consumer_nvcsw += c->nvcsw.load();
+        out->consumer_nivcsw += c->nivcsw.load();
+        const uint64_t qh = c->queued_high.load();
+        if (qh > out->queue_high_points) out->queue_high_points = qh;
+    }
+    if (run_s > 0 && out->consumers) out->consumer_busy_mean = busy_sum / run_s / out->consumers;
+    for (const Worker *w : s->workers) {
+        const double hm = (double)w->host_us_max.load() * 1e-3, im = (double)w->ingest_us_max.load() * 1e-3;
+        if (hm > out->host_ms_max) out->host_ms_max = hm;
+        if (im > out->ingest_ms_max) out->ingest_ms_max = im;
+        const uint64_t l = w->launches.load();
+        if (l > 1) out->host_ms_mean += (double)w->host_us_sum.load() * 1e-3 / (double)(l - 1) / (double)s->workers.size();
+        out->late_launches += w->late.load();
+    }
+    out->run_seconds = run_s;
+    out->numa_nodes = (uint32_t)s->numa_nodes;
+    out->effective_cpus = s->cpus > 0 ? s->cpus : effective_cpus();
     return 0;
 }
 

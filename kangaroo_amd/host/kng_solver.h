@@ -45,8 +45,9 @@ typedef struct kngs_config {
                                already in a restored table */
     uint64_t max_launches;  /* per GPU, 0 = until solved or stopped */
     uint32_t warmup_launches; /* benchmarks: launches run and discarded by kngs_prepare, outside any timing */
-    uint32_t reserved;
+    uint32_t flags;           /* KNGS_FLAG_* */
 } kngs_config;
+#define KNGS_FLAG_NO_PIN 1u /* do not confine the table threads to NUMA nodes (default: consumer i of n -> node i*nodes/n) */
 
 typedef struct kngs_stats {
     uint64_t jumps;            /* incl. the count restored from a work file */
@@ -114,6 +115,25 @@ int kngs_gpu_stats(const kngs_solver *s, int gpu, uint64_t *launches, double *ke
 /* an option of one GPU's engine as kng_get_option reads it ("group", "lanes", "share", "dsplit", "asm", ...): lets a caller
  * name the walk kernel that ran instead of assuming the defaults.  Valid after kngs_prepare / kngs_start. */
 int kngs_gpu_option(const kngs_solver *s, int gpu, const char *key, int64_t *value);
+/* Is the host keeping up?  (bench.py --gpus N prints these so that an N-GPU line diagnoses itself.)
+ *   host_ms_*       a GPU thread's own work per launch -- next launch, drain, ingest, replacements -- i.e. everything
+ *                   between two kng_wait calls; the GPU never idles while this stays below the kernel time
+ *   late_launches   launches for which it did not (the kernel had finished before its host thread came back for it)
+ *   ingest_ms_max   the slowest hand-over of one launch's points to the consumers
+ *   queue_high_points  most points ever waiting in one consumer's queue
+ *   consumer_busy_* fraction of the run a consumer thread spent inserting (1.0 = saturated) */
+typedef struct kngs_host_stats_t {
+    double host_ms_max, host_ms_mean, ingest_ms_max;
+    uint64_t late_launches, queue_high_points;
+    double consumer_busy_max, consumer_busy_mean, run_seconds;
+    uint32_t consumers, numa_nodes; /* numa_nodes: nodes the consumers were confined to (0/1 = not pinned) */
+    /* the kernel's account of the consumer threads, summed, available once they have ended (kngs_stop): seconds on a CPU,
+     * seconds runnable but waiting for one, seconds inside batches (busy), voluntary / involuntary context switches */
+    double consumer_cpu_s, consumer_runq_s, consumer_busy_s;
+    uint64_t consumer_nvcsw, consumer_nivcsw;
+    double effective_cpus; /* CPUs the process may use: hardware threads cut by affinity and the cgroup quota (sizes the default consumer count) */
+} kngs_host_stats_t;
+int kngs_host_stats(const kngs_solver *s, kngs_host_stats_t *out);
 /* points each consumer thread has taken off its queue; returns the number of consumers */
 int kngs_consumer_load(const kngs_solver *s, uint64_t *handled, int cap);
 

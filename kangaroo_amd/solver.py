@@ -37,7 +37,7 @@ class _Config(C.Structure):
     _fields_ = [("range_start", C.c_uint64 * 4), ("range_end", C.c_uint64 * 4), ("key_x", C.c_uint64 * 4),
                 ("key_y", C.c_uint64 * 4), ("dp", C.c_int32), ("n_gpus", C.c_int32), ("gpu_ids", C.c_int32 * MAX_GPUS),
                 ("grid_x", C.c_int32), ("grid_y", C.c_int32), ("max_found", C.c_uint32), ("consumers", C.c_int32),
-                ("seed", C.c_uint64), ("max_launches", C.c_uint64), ("warmup_launches", C.c_uint32), ("reserved", C.c_uint32)]
+                ("seed", C.c_uint64), ("max_launches", C.c_uint64), ("warmup_launches", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class _Stats(C.Structure):
@@ -48,6 +48,14 @@ class _Stats(C.Structure):
                 ("herd_loaded", C.c_uint64), ("herd_created", C.c_uint64), ("table_bytes", C.c_uint64),
                 ("warmup_jumps", C.c_uint64), ("audits", C.c_uint64), ("audited_kangaroos", C.c_uint64),
                 ("audit_mismatches", C.c_uint64)]
+
+
+class _HostStats(C.Structure):
+    _fields_ = [("host_ms_max", C.c_double), ("host_ms_mean", C.c_double), ("ingest_ms_max", C.c_double),
+                ("late_launches", C.c_uint64), ("queue_high_points", C.c_uint64), ("consumer_busy_max", C.c_double),
+                ("consumer_busy_mean", C.c_double), ("run_seconds", C.c_double), ("consumers", C.c_uint32), ("numa_nodes", C.c_uint32),
+                ("consumer_cpu_s", C.c_double), ("consumer_runq_s", C.c_double), ("consumer_busy_s", C.c_double),
+                ("consumer_nvcsw", C.c_uint64), ("consumer_nivcsw", C.c_uint64), ("effective_cpus", C.c_double)]
 
 
 class _AuditResult(C.Structure):
@@ -100,6 +108,7 @@ def _lib() -> C.CDLL:
         L.kngs_get_stats.argtypes = [C.c_void_p, C.POINTER(_Stats)]
         L.kngs_save.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.kngs_audit.argtypes = [C.c_void_p, C.c_int, C.POINTER(_AuditResult)]
+        L.kngs_host_stats.argtypes = [C.c_void_p, C.POINTER(_HostStats)]
         L.kngs_collision_key.argtypes = [C.c_void_p, _U64P, _U64P, _U64P]
         L.kngs_last_error.restype = C.c_char_p
         L.kngs_gpu_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
@@ -222,12 +231,12 @@ class Solver:
     """Kangaroo::SolveKeyGPU for N GPUs (Kangaroo.cpp:510-644, :1019-1063) over the C-ABI engine."""
 
     def __init__(self, range_start: int, range_end: int, key, *, gpus=(0,), grid=(0, 0), dp: int = -1, max_found: int = 0,
-                 consumers: int = 0, seed: int = 0, max_launches: int = 0, warmup_launches: int = 0):
+                 consumers: int = 0, seed: int = 0, max_launches: int = 0, warmup_launches: int = 0, flags: int = 0):
         """seed 0 (default) draws a herd seed like the reference does from the clock (main.cpp:177); stats()["seed"]
         reports it.  Pass a fixed seed only for tests and benchmarks: equal seeds rebuild equal herds."""
         self._L = _lib()
         cfg = _Config(dp=dp, n_gpus=len(gpus), grid_x=grid[0], grid_y=grid[1], max_found=max_found, consumers=consumers,
-                      seed=seed & ((1 << 64) - 1), max_launches=max_launches, warmup_launches=warmup_launches)
+                      seed=seed & ((1 << 64) - 1), max_launches=max_launches, warmup_launches=warmup_launches, flags=flags)
         for name, v in (("range_start", range_start), ("range_end", range_end), ("key_x", key[0]), ("key_y", key[1])):
             for i in range(4):
                 getattr(cfg, name)[i] = (v >> (64 * i)) & ((1 << 64) - 1)
@@ -330,3 +339,9 @@ class Solver:
         out = {k: getattr(r, k) for k, _ in _AuditResult._fields_ if k not in ("first_bad", "reserved", "n_first_bad")}
         out["first_bad"] = [(int(v) >> 56, int(v) & ((1 << 56) - 1)) for v in list(r.first_bad)[: r.n_first_bad]]
         return out
+
+    def host_stats(self) -> dict:
+        """kngs_host_stats: is the host keeping up (host ms per launch, late launches, queue high-water, consumer load)"""
+        h = _HostStats()
+        self._check(self._L.kngs_host_stats(self._h, C.byref(h)))
+        return {k: (round(getattr(h, k), 4) if isinstance(getattr(h, k), float) else getattr(h, k)) for k, _ in _HostStats._fields_ if k != "reserved"}

@@ -41,13 +41,15 @@ def test_reference_program_solves_25_keys_one_engine_per_key(kng):
     start, end, pubs = int(lines[0], 16), int(lines[1], 16), lines[2:]
     assert len(pubs) == 25
     t0 = time.time()
-    out = subprocess.run([exe, "-t", "0", "-gpu", "-g", "32,128", cfg], capture_output=True, text=True, timeout=900)
+    # KNG_TRACE: kng_set_params reports its engine's buffers on stderr -- one line per GPUEngine the program creates
+    out = subprocess.run([exe, "-t", "0", "-gpu", "-g", "32,128", cfg], capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, KNG_TRACE="1"))
     dt = time.time() - t0
     text = out.stdout
     assert "Failed" not in text, text[-2000:]
     found = re.findall(r"Key#\s*(\d+) \[\d+.\]Pub:\s+0x([0-9A-Fa-f]+)\s*\n\s+Priv: 0x([0-9A-Fa-f]+)", text)
     assert len(found) == 25, (len(found), text[-2500:] + out.stderr[-500:])
-    assert text.count("GPU: GPU #0") == 25  # one engine per key
+    assert out.stderr.count("kng: planes") == 25, out.stderr[-1500:]  # one engine per key (the banner is printed for key 0 only, Kangaroo.cpp:525-526)
     for i, (idx, pub, priv) in enumerate(found):
         assert int(idx) == i and pub.upper() == pubs[i].upper()
         k = int(priv, 16)

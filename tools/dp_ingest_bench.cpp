@@ -3,6 +3,9 @@
 // each hands `points` synthetic engine records per "launch" to kngs_ingest, optionally paced at --launch-ms.
 // build: g++ -O2 -std=c++17 -Iinclude -Ikangaroo_amd/host -o tools/dp_ingest_bench tools/dp_ingest_bench.cpp \
 //            -Lkangaroo_amd/lib -lkangaroo_host -lkangaroo_hip -Wl,-rpath,'$ORIGIN/../kangaroo_amd/lib' -lpthread
+#include <sys/resource.h>
+
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -26,6 +29,14 @@ int main(int argc, char **argv) {
     int feeders = 8, consumers = 0, launches = 40;
     uint32_t points = 262144;
     double launch_ms = 0;
+    uint32_t flags = 0;
+    for (int i = 1; i < argc; i++)
+        if (!strcmp(argv[i], "--no-pin")) { // consumers not confined to NUMA nodes
+            flags |= KNGS_FLAG_NO_PIN;
+            for (int j = i; j + 1 < argc; j++) argv[j] = argv[j + 1];
+            argc--;
+            i--;
+        }
     for (int i = 1; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "--feeders")) feeders = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "--consumers")) consumers = atoi(argv[i + 1]);
@@ -43,12 +54,14 @@ int main(int argc, char **argv) {
     cfg.n_gpus = 1;
     cfg.consumers = consumers;
     cfg.seed = 1;
+    cfg.flags = flags;
     kngs_solver *s = nullptr;
     if (kngs_create(&cfg, &s) != 0 || kngs_start_ingest(s, feeders) != 0) {
         fprintf(stderr, "%s\n", kngs_last_error());
         return 1;
     }
     std::vector<double> fed_s(feeders), lag_ms(feeders);
+    std::vector<std::vector<double>> per_launch(feeders, std::vector<double>(launches, 0.0));
     std::vector<std::thread> th;
     const auto t0 = std::chrono::steady_clock::now();
     for (int f = 0; f < feeders; f++)
@@ -78,7 +91,9 @@ int main(int argc, char **argv) {
                     fprintf(stderr, "%s\n", kngs_last_error());
                     return;
                 }
-                busy += std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+                const double took = std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count();
+                busy += took;
+                per_launch[f][l] = took;
             }
             fed_s[f] = busy;
             lag_ms[f] = lag;
@@ -104,7 +119,29 @@ int main(int argc, char **argv) {
     printf("table: %llu items, %.2f GiB = %.1f B/item; same-x rejects %llu\n", (unsigned long long)stt.table_items, stt.table_bytes / 1073741824.0,
            (double)stt.table_bytes / (double)(stt.table_items ? stt.table_items : 1), (unsigned long long)stt.same_herd);
     printf("consumer load: min %llu max %llu points\n", (unsigned long long)lmin, (unsigned long long)lmax);
+    { // the slowest hand-overs, and when they happened
+        std::vector<std::pair<double, int>> all;
+        for (int f = 0; f < feeders; f++)
+            for (int l = 0; l < launches; l++) all.emplace_back(per_launch[f][l], f * 100000 + l);
+        std::sort(all.begin(), all.end(), [](auto &a, auto &b) { return a.first > b.first; });
+        printf("slowest hand-overs (ms @ feeder:launch):");
+        for (size_t i = 0; i < 6 && i < all.size(); i++) printf(" %.2f@%d:%d", all[i].first * 1e3, all[i].second / 100000, all[i].second % 100000);
+        printf("; median %.2f ms\n", all[all.size() / 2].first * 1e3);
+    }
+    kngs_host_stats_t hs;
+    if (kngs_host_stats(s, &hs) == 0)
+        printf("consumers confined to %u NUMA node(s); the process may use %.1f CPUs\n", hs.numa_nodes, hs.effective_cpus);
+    if (kngs_host_stats(s, &hs) == 0)
+        printf("host stats: consumers busy %.0f %% mean / %.0f %% max of the run; most points waiting in one queue %llu; slowest hand-over of a launch %.2f ms\n",
+               100 * hs.consumer_busy_mean, 100 * hs.consumer_busy_max, (unsigned long long)hs.queue_high_points, hs.ingest_ms_max);
+    struct rusage ru;
+    getrusage(RUSAGE_SELF, &ru);
+    printf("process: %.2f s user + %.2f s system CPU over %.2f s wall, %ld minor page faults\n", ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6,
+           ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6, t_all, ru.ru_minflt);
     kngs_stop(s);
+    if (kngs_host_stats(s, &hs) == 0)
+        printf("consumer threads, summed: %.2f s inside batches, of which %.2f s on a CPU and %.2f s runnable but waiting for one; %llu voluntary / %llu involuntary context switches\n",
+               hs.consumer_busy_s, hs.consumer_cpu_s, hs.consumer_runq_s, (unsigned long long)hs.consumer_nvcsw, (unsigned long long)hs.consumer_nivcsw);
     kngs_destroy(s);
     return 0;
 }

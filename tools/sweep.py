@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--dsplit", type=int, default=-1, help="-1 auto / 0 / 1: low-word streaming of the distances")
     ap.add_argument("--jd-bits", type=int, default=40, help="size of the synthetic jump distances: 54+ makes both distance words stream (the non-dsplit kernels)")
     ap.add_argument("--lanes", default="", help="explicit lane counts (ragged groups); overrides --groups")
-    ap.add_argument("--dp-ring", default="0", help="comma list of 0/1: DP records into a device buffer + copy / straight into pinned host memory")
+    ap.add_argument("--dp-ring", default="1", help="comma list of 0/1: DP records into a device buffer + copy / straight into pinned host memory")
     ap.add_argument("--asm", default="1", help="comma list of 0/1: compiler-scheduled loop / scheduled asm loop")
     a = ap.parse_args()
     gx, gy = (int(v) for v in a.grid.split(","))
