@@ -61,6 +61,7 @@ struct WalkArgs {
     uint32_t group; // nominal G (exact when lanes divides the herd)
     uint64_t n_kang; // N: lane t walks kangaroos t, t+L, ... < N, i.e. ceil((N-t)/L) of them (uniform per wave: L is a multiple of 64)
     uint32_t nsteps;
+    uint32_t resume; // 1: the previous launch left the prefix products of the next jump's dx in the S planes (ascending order): no pass 0
     uint64_t asm_args; // device address of this launch's WalkAsmArgs (the scheduled loop reads its constants with s_load)
 };
 
@@ -262,7 +263,7 @@ KNG_DEV void walk_core(const WalkArgs &a, const uint64_t *tab, uint64_t *dlo, ui
 // jump distance is below 2^58 (kng_set_params; 2^50 for the compiler-scheduled loop, whose carry path is a divergent
 // read-modify-write): ranges up to 115 bits, BASELINE configs[3] included.  Results are identical.
 //
-// ASM = true (option "asm", the default): the per-kangaroo loop of every step but the last runs as ONE scheduled asm
+// ASM = true (option "asm", the default): the per-kangaroo loop of every step runs as ONE scheduled asm
 // statement (kng_walk_asm.h, generated by tools/gen_walk_asm.py) instead of the compiler-scheduled loop below -- same
 // data flow, same results, no hazard nops and a third of the register moves.  Its short arithmetic forms flag the lanes
 // for which they are not exact; the statement then returns BEFORE storing anything of that iteration and the wave runs
@@ -276,15 +277,24 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
     // SHARE: every thread reaches the barriers; lanes beyond L walk nothing (wave-uniform: L % 64 == 0)
     const uint32_t G = t < L ? (uint32_t)((a.n_kang - t + L - 1) / L) : 0;
 
-    // pass 0: prefix products of dx in ascending order (GPUCompute.h:52-61 + GPUMath.h:1173-1177)
+    // pass 0: prefix products of dx in ascending order (GPUCompute.h:52-61 + GPUMath.h:1173-1177).
+    // Round 4: EVERY step of a launch, the last one included, leaves the products of the next jump's dx behind, and an even
+    // number of steps leaves them in ascending order -- exactly what pass 0 computes.  The host then starts the next launch
+    // with `resume` (nothing touched the herd, the table or the S planes in between: kng_launch) and the pass -- 1/64 of a
+    // launch's x reads and product writes, one multiplication per kangaroo -- is skipped; the lane only re-reads its
+    // whole-batch product, the last slot of its chain.
     fe acc = fe_one();
-    for (uint32_t g = 0; g < G; g++) {
-        const size_t idx = (size_t)g * L + t;
-        const fe x = ld_fe(a.x01, a.x23, idx);
-        const uint32_t j = (uint32_t)x.v[0] & (KNG_NB_JUMP - 1);
-        const fe dx = fe_sub(x, lds_fe(tab, JT_JX, j));
-        acc = g ? fe_mul(acc, dx) : dx;
-        st_prod(a.s01, a.s23, idx, acc);
+    if (a.resume) {
+        if (G) acc = ld_prod(a.s01, a.s23, (size_t)(G - 1) * L + t);
+    } else {
+        for (uint32_t g = 0; g < G; g++) {
+            const size_t idx = (size_t)g * L + t;
+            const fe x = ld_fe(a.x01, a.x23, idx);
+            const uint32_t j = (uint32_t)x.v[0] & (KNG_NB_JUMP - 1);
+            const fe dx = fe_sub(x, lds_fe(tab, JT_JX, j));
+            acc = g ? fe_mul(acc, dx) : dx;
+            st_prod(a.s01, a.s23, idx, acc);
+        }
     }
 
     for (uint32_t step = 0; step < a.nsteps; step++) {
@@ -362,12 +372,12 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
             inv = fe_inv(acc);
         }
         const bool backward = !(step & 1); // reverse of the pass that produced the products
-        const bool last = (step + 1 == a.nsteps);
+        const bool last = false; // (rounds 1-3: the last step of a launch skipped the products of the next jump; see pass 0)
         // slot(k): kangaroo processed k-th in this pass
         auto slot = [&](uint32_t k) -> size_t { return (size_t)(backward ? (G - 1 - k) : k) * L + t; };
 
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (ASM && !last) {
+        if (ASM) {
             // G is wave-uniform (L is a multiple of 64); the statement keeps its loop counter in an SGPR
             const uint32_t Gs = __builtin_amdgcn_readfirstlane(G);
             // (readfirstlane: the "s" operands must be provably wave-uniform for the compiler)
@@ -771,6 +781,7 @@ struct kng_engine {
     // state
     uint64_t dp_mask = 0;
     bool have_params = false, have_herd = false;
+    bool products_valid = false; // the S planes hold the prefix products the next launch needs (left by the previous launch, nothing touched since)
     bool outstanding = false; // launched, not yet waited
     int slot_next = 0;        // DP buffer the next launch writes
     int slot_ready = -1;      // DP buffer of the most recently waited launch
@@ -1045,6 +1056,7 @@ uint64_t kng_memory_bytes(const kng_engine *h) { return h ? h->bytes : 0; }
 int kng_set_option(kng_engine *h, const char *key, int64_t value) {
     if (!h || !key) return fail(KNG_E_ARG, "null argument");
     if (h->outstanding) return fail(KNG_E_STATE, "cannot change options while a launch is outstanding");
+    h->products_valid = false; // geometry, layout or loop may change: the next launch recomputes its products
     std::string k(key);
     if (k == "group") {
         if (value < 1 || (value & (value - 1)) || (h->n % (uint64_t)value)) return fail(KNG_E_ARG, "group must be a power of two dividing the herd");
@@ -1149,6 +1161,7 @@ int kng_set_params(kng_engine *h, uint64_t dp_mask, const uint64_t *jd, const ui
     int rc = upload_loop_args(h); // (synchronises the stream: `tab` lives on this stack)
     if (rc != KNG_OK) return rc;
     h->have_params = true;
+    h->products_valid = false; // another jump table: the stored products are those of the old one's dx
     return KNG_OK;
 }
 
@@ -1188,6 +1201,7 @@ int kng_set_kangaroos_range(kng_engine *h, uint64_t first, uint64_t count, const
         HIP_TRY(hipStreamSynchronize(h->walk)); // staging buffer is reused
     }
     // the herd counts as loaded once its last kangaroo has been written (ranges are normally uploaded in order)
+    h->products_valid = false;
     if (first + count == h->n) h->have_herd = true;
     return KNG_OK;
 }
@@ -1255,6 +1269,7 @@ int kng_build_herd(kng_engine *h, int range_power, uint64_t seed, const uint64_t
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->walk));
     h->have_herd = true;
+    h->products_valid = false;
     return KNG_OK;
 }
 
@@ -1295,8 +1310,9 @@ int kng_audit_herd(kng_engine *h, uint64_t *n_bad, uint64_t *bad_idx, uint32_t b
     a.dlo = dplane(h, 0); a.dhi = dplane(h, 1);
     a.recs = nullptr;
     h->last_audit_ms = 0.f;
+    h->products_valid = false;
     uint32_t recorded = 0;
-    // the S planes are free between launches: every launch starts with its own product pass
+    // the S planes are borrowed: the next launch starts with its own product pass
     return run_audit<false>(h, h->walk, a, scratch.as<v16>(), plane(h, 5), plane(h, 6), h->n, h->lanes, n_bad, bad_idx, bad_cap, 0, &recorded);
 }
 
@@ -1337,6 +1353,7 @@ int kng_set_kangaroo(kng_engine *h, uint64_t kidx, const uint64_t x[4], const ui
     if (kidx >= h->n) return fail(KNG_E_ARG, "kIdx %llu out of range", (unsigned long long)kidx);
     HIP_TRY(hipSetDevice(h->dev));
     const fe fx{{x[0], x[1], x[2], x[3]}}, fy{{y[0], y[1], y[2], y[3]}};
+    h->products_valid = false; // the next launch starts with its own product pass again
     hipLaunchKernelGGL(kng_patch_kernel, dim3(1), dim3(1), 0, h->walk, plane(h, 0), plane(h, 1), plane(h, 2), plane(h, 3), plane(h, 4),
                        h->n, kidx, fx, fy, make_ulonglong2(d[0], d[1]));
     HIP_TRY(hipGetLastError());
@@ -1362,6 +1379,8 @@ int kng_launch(kng_engine *h) {
     a.group = h->group;
     a.n_kang = h->n;
     a.nsteps = h->nsteps;
+    a.resume = h->products_valid ? 1 : 0;
+    h->products_valid = (h->nsteps % 2) == 0; // this launch leaves them in ascending order when its passes pair up
     a.asm_args = (uint64_t)(h->asm_args + s);
     HIP_TRY(hipMemsetAsync(h->dp_count[s], 0, 8, h->walk)); // GPUEngine.cu:543 (+ the launch's exact-path exit counter)
     HIP_TRY(hipEventRecord(h->ev_start[s], h->walk));

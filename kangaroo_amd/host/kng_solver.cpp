@@ -530,19 +530,19 @@ void worker_main(kngs_solver *s, Worker *w) {
     Clock::time_point host_t0{};
     bool have_host_t0 = false;
     for (;;) {
+        uint64_t host_us = 0;
         if (have_host_t0) { // the host's share of the last cycle: everything between two kng_wait calls
-            const uint64_t us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - host_t0).count();
-            w->host_us_sum += us;
-            if (us > w->host_us_max.load(std::memory_order_relaxed)) w->host_us_max.store(us, std::memory_order_relaxed);
+            host_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - host_t0).count();
+            w->host_us_sum += host_us;
+            if (host_us > w->host_us_max.load(std::memory_order_relaxed)) w->host_us_max.store(host_us, std::memory_order_relaxed);
         }
         if (kng_wait(w->eng, 0) != KNG_OK) return bail(std::string("kng_wait: ") + kng_last_error());
         float ms = 0;
         kng_last_kernel_ms(w->eng, &ms);
-        if (have_host_t0) {
-            const uint64_t us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - host_t0).count();
-            // the kernel this wait returned from was started at host_t0: a host cycle longer than it left the GPU idle
-            if ((double)us > (double)ms * 1000.0 * 1.10 + 500.0) w->late++;
-        }
+        // The kernel this wait returned from was started FIRST in that host share; while the share is shorter than the
+        // kernel the device never waits for this thread.  (Measured against the kernel's own duration, not the time to the
+        // wait's return: on a device shared with other engines that includes their kernels.)
+        if (have_host_t0 && (double)host_us > (double)ms * 1000.0) w->late++;
         host_t0 = Clock::now();
         have_host_t0 = true;
         w->kernel_us_sum += (uint64_t)(ms * 1000.0f + 0.5f);
@@ -1244,52 +1244,63 @@ int kngs_audit(kngs_solver *s, int with_table, kngs_audit_result *out) {
         out->kangaroo_mismatches += bad;
     }
     if (rc == 0 && with_table) {
-        // every table entry back to an engine record: x limbs 0-1 + the bucket bits, device distance, type; compare mode 1
-        const uint64_t C = 1u << 21;
-        std::vector<kng_dp_record> recs;
-        recs.reserve(C);
-        std::vector<kngt_entry> ent;
+        // every table entry back to an engine record: x limbs 0-1 + the bucket bits, device distance, type; compare mode 1.
+        // Blocks of buckets are converted by a few threads side by side (decode + one addition mod n per entry), then
+        // audited on the engines in turn.
+        const uint32_t BLOCK = 8192, PARTS = 8; // buckets per block, threads per block
         size_t turn = 0;
-        auto flush = [&]() {
-            if (recs.empty() || rc) return;
-            Worker *w = s->workers[turn++ % s->workers.size()];
-            uint64_t bad = 0;
-            if (kng_audit_points(w->eng, recs.data(), recs.size(), &bad, nullptr, 0) != KNG_OK) {
-                rc = fail("kng_audit_points: %s", kng_last_error());
-                return;
-            }
-            int64_t us = 0;
-            kng_get_option(w->eng, "audit_us", &us);
-            out->table_ms += (double)us * 1e-3;
-            out->table_points += recs.size();
-            out->table_mismatches += bad;
-            recs.clear();
-        };
-        for (uint32_t b = 0; b < KNGT_BUCKETS && rc == 0; b++) {
-            const uint32_t cnt = kngt_bucket_count(s->table, b);
-            if (!cnt) continue;
-            ent.resize(cnt);
-            const uint32_t got = kngt_bucket_entries(s->table, b, ent.data(), cnt);
-            for (uint32_t i = 0; i < got; i++) {
-                uint64_t d[4], dd[4];
-                uint32_t type = 0;
-                kngt_decode(ent[i].d, d, &type);
-                if (type & 1) kngh_add_order(d, s->wild_offset.v, dd); else std::memcpy(dd, d, 32);
-                if (dd[2] | dd[3]) { // not a distance an engine can have produced
-                    out->table_points++;
-                    out->table_mismatches++;
-                    continue;
+        std::vector<std::vector<kng_dp_record>> part(PARTS);
+        std::vector<uint64_t> unfit(PARTS);
+        for (uint32_t b0 = 0; b0 < KNGT_BUCKETS && rc == 0; b0 += BLOCK) {
+            std::vector<std::thread> th;
+            for (uint32_t p = 0; p < PARTS; p++)
+                th.emplace_back([&, p] {
+                    std::vector<kng_dp_record> &recs = part[p];
+                    recs.clear();
+                    unfit[p] = 0;
+                    std::vector<kngt_entry> ent;
+                    const uint32_t lo = b0 + p * (BLOCK / PARTS), hi = lo + BLOCK / PARTS;
+                    for (uint32_t b = lo; b < hi; b++) {
+                        const uint32_t cnt = kngt_bucket_count(s->table, b);
+                        if (!cnt) continue;
+                        ent.resize(cnt);
+                        const uint32_t got = kngt_bucket_entries(s->table, b, ent.data(), cnt);
+                        for (uint32_t i = 0; i < got; i++) {
+                            uint64_t d[4], dd[4];
+                            uint32_t type = 0;
+                            kngt_decode(ent[i].d, d, &type);
+                            if (type & 1) kngh_add_order(d, s->wild_offset.v, dd); else std::memcpy(dd, d, 32);
+                            if (dd[2] | dd[3]) { // not a distance an engine can have produced
+                                unfit[p]++;
+                                continue;
+                            }
+                            kng_dp_record r;
+                            r.x[0] = ent[i].x[0]; r.x[1] = ent[i].x[1]; r.x[2] = b; r.x[3] = 0;
+                            r.d[0] = dd[0]; r.d[1] = dd[1];
+                            r.kidx = type & 1;
+                            r.reserved = 1;
+                            recs.push_back(r);
+                        }
+                    }
+                });
+            for (auto &t : th) t.join();
+            for (uint32_t p = 0; p < PARTS && rc == 0; p++) {
+                out->table_points += unfit[p];
+                out->table_mismatches += unfit[p];
+                if (part[p].empty()) continue;
+                Worker *w = s->workers[turn++ % s->workers.size()];
+                uint64_t bad = 0;
+                if (kng_audit_points(w->eng, part[p].data(), part[p].size(), &bad, nullptr, 0) != KNG_OK) {
+                    rc = fail("kng_audit_points: %s", kng_last_error());
+                    break;
                 }
-                kng_dp_record r;
-                r.x[0] = ent[i].x[0]; r.x[1] = ent[i].x[1]; r.x[2] = b; r.x[3] = 0;
-                r.d[0] = dd[0]; r.d[1] = dd[1];
-                r.kidx = type & 1;
-                r.reserved = 1;
-                recs.push_back(r);
-                if (recs.size() == C) flush();
+                int64_t us = 0;
+                kng_get_option(w->eng, "audit_us", &us);
+                out->table_ms += (double)us * 1e-3;
+                out->table_points += part[p].size();
+                out->table_mismatches += bad;
             }
         }
-        flush();
     }
     if (running) release_workers(s);
     out->seconds = seconds_since(t0);

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import (M128, N_ORDER, P, array_to_ints, device_distances, dp_multiset, ints_to_array, ref_binary, walk_fixture)
+from helpers import (M128, N_ORDER, P, array_to_ints, device_distances, dp_multiset, host_distance, ints_to_array, ref_binary, walk_fixture)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -975,3 +975,65 @@ def test_device_herd_creation(kng, orc, rp, grid, group):
         e2.CreateHerdOnDevice(rp, (kx, ky), seed=100)
         b = e2.GetKangaroos(raw=True)
     assert np.array_equal(a[0], px) and not np.array_equal(b[2], d_dev)
+
+
+@pytest.mark.parametrize("use_asm,rp", [(1, 72), (0, 72), (1, 125)])
+def test_products_carried_from_launch_to_launch(kng, orc, use_asm, rp):
+    """Round 4: a launch leaves the prefix products of the NEXT jump's dx in the product planes and the following launch
+    starts from them instead of recomputing them (WalkArgs.resume) -- unless anything touched the herd, the jump table, the
+    geometry or the planes in between.  Every such event, and an odd number of steps (products left in descending order),
+    must bring the product pass back; the state and the DP multiset after every launch equal the oracle's."""
+    grid, G = (4, 8), 16
+    n = grid[0] * grid[1] * 128
+    x, y, true_d, wild_offset = _seeded_herd(orc, n, rp, seed=31337 + rp)
+    jd, jx, jy, _ = orc.jump_table(rp)
+    jd2, jx2, jy2, _ = orc.jump_table(rp - 8)
+    mask = orc.dp_mask(5)
+    eng = kng.GPUEngine(grid[0], grid[1], 0, 1 << 17, group=G, asm=use_asm)
+    eng.SetParams(mask, jd, jx, jy)
+    eng.SetWildOffset(wild_offset)
+    eng.SetKangaroos(x, y, ints_to_array(true_d))
+    ox, oy = x.copy(), y.copy()
+    od = ints_to_array(device_distances(true_d, wild_offset), 2)
+    key = lambda r: (int(r["kidx"]), tuple(int(v) for v in r["x"]), tuple(int(v) for v in r["d"]))  # noqa: E731
+    tab = [jd, jx, jy]
+
+    def launch_and_compare(what, steps=64):
+        eng.callKernel()
+        eng.wait()
+        got = eng.drain(raw=True)
+        want, total = orc.walk(ox, oy, od, steps, tab[0], tab[1], tab[2], mask, dp_cap=1 << 22)
+        assert len(got) == total and sorted(map(key, got)) == sorted(map(key, want)), what
+        gx, gy, gd = eng.GetKangaroos(raw=True)
+        assert np.array_equal(gx, ox) and np.array_equal(gy, oy) and np.array_equal(gd, od), what
+
+    launch_and_compare("first launch: product pass")
+    launch_and_compare("second launch: resumes")
+    launch_and_compare("third launch: resumes")
+    # one kangaroo replaced between launches (kng_set_kangaroo): its dx changed, the stored products are stale
+    k = 4 * G + 3
+    nx, ny, nd = x[k ^ 2].copy(), y[k ^ 2].copy(), od[k ^ 2].copy()  # a valid point of the same type (k ^ 2 keeps parity)
+    ox[k], oy[k], od[k] = nx, ny, nd
+    from helpers import from_limbs
+
+    eng.SetKangaroo(k, from_limbs(nx), from_limbs(ny), host_distance(from_limbs(nd), k, wild_offset))
+    launch_and_compare("after SetKangaroo")
+    launch_and_compare("resumes again")
+    # the audit borrows the product planes
+    _, kx, ky = orc.pubkey(1)
+    eng.audit_setup((kx, ky))
+    eng.audit_herd(cap=0)  # (mismatches are expected: the herd's key is not 1*G; only the planes matter here)
+    launch_and_compare("after an audit")
+    # an odd number of steps leaves the products in descending order
+    eng.set_option("steps", 33)
+    launch_and_compare("33 steps", 33)
+    launch_and_compare("33 steps again", 33)
+    eng.set_option("steps", 64)
+    launch_and_compare("back to 64")
+    launch_and_compare("resumes")
+    # another jump table
+    tab[:] = [jd2, jx2, jy2]
+    eng.SetParams(mask, jd2, jx2, jy2)
+    launch_and_compare("new table")
+    launch_and_compare("resumes with the new table")
+    eng.close()

@@ -445,3 +445,35 @@ def test_configs4_save_restore_at_the_default_herd(sv, orc, tmp_path):
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "r03_configs4_default_herd.txt"), "w") as f:
         f.write("# tests/test_gpu_solver.py::test_configs4_save_restore_at_the_default_herd (BASELINE configs[4] on one MI355X)\n" + "\n".join(lines) + "\n")
+
+
+def test_solver_audit_herd_and_table(sv):
+    """kngs_audit: while the solver RUNS the GPUs pause at a launch boundary and every kangaroo is
+    re-derived from its distance; after the run the same plus every table entry (what an entry keeps of x: 128 + 18 bits).
+    A bogus entry planted in the table and a corrupted kangaroo are both found."""
+    import kangaroo_amd.hostlib as hl
+
+    start = 0x5A5A000000000000000000
+    key = start + 0x1F2E3D4C5B6A79881
+    grid = (64, 64)
+    n = grid[0] * grid[1] * 128
+    s = sv.Solver(start, start + (1 << 70) - 1, hl.pubkey(key)[1:], gpus=(0, 0), grid=grid, dp=8, seed=77, max_launches=40)
+    s.start()
+    mid = s.audit(False)          # running: parks both GPU threads, audits both herds, resumes
+    assert mid["kangaroos"] == 2 * n and mid["kangaroo_mismatches"] == 0 and mid["table_points"] == 0
+    rc = s.wait(120)
+    assert rc == 2, rc            # 70 bits are not solved in 40 launches
+    full = s.audit(True)
+    st = s.stats()
+    assert full["kangaroos"] == 2 * n and full["kangaroo_mismatches"] == 0
+    assert full["table_mismatches"] == 0 and full["table_points"] > 100000
+    s.stop()
+    st = s.stats()
+    assert full["table_points"] == st["table_items"], (full, st)
+    assert st["audits"] == 2 and st["audit_mismatches"] == 0 and st["audited_kangaroos"] == 4 * n
+    # a planted entry: right format, wrong point
+    t = s.table()
+    assert t.add(0x1234567890ABCDEF1234567890ABCDEF00000000000000000000000000012345, 0x777, 0)[0] == sv.ADD_OK
+    bad = s.audit(True)
+    assert bad["table_points"] == full["table_points"] + 1 and bad["table_mismatches"] == 1 and bad["kangaroo_mismatches"] == 0
+    s.close()

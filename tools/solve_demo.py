@@ -22,6 +22,8 @@ ap.add_argument("--dp", type=int, default=-1)
 ap.add_argument("--save", default="")
 ap.add_argument("--load", default="", help="resume from a work file (ours or the reference's)")
 ap.add_argument("--input", default="", help="reference-style input file: start, end, public key")
+ap.add_argument("--audit-every", type=float, default=0, help="seconds between whole-herd audits while running (0 = only at the end)")
+ap.add_argument("--no-audit", action="store_true", help="skip the closing whole-run audit (herd + every table entry)")
 a = ap.parse_args()
 
 P = (1 << 256) - (1 << 32) - 977
@@ -50,15 +52,31 @@ s.start()
 st = s.stats()
 print(f"range 2^{st['range_power']}, {st['kangaroos']} kangaroos, dp {st['dp']}, expected ~2^{st['range_power'] / 2 + 1.05:.1f} jumps", flush=True)
 rc = 0
+import math
+
+next_audit = a.audit_every or float("inf")
 while rc == 0 and time.time() - t0 < a.max_seconds:
-    rc = s.wait(20)
+    rc = s.wait(min(20, max(0.5, next_audit - (time.time() - t0))))
     st = s.stats()
-    import math
+    if rc == 0 and time.time() - t0 >= next_audit:
+        # the GPUs pause at a launch boundary (as for a save), every kangaroo is re-derived from its distance, they resume
+        au = s.audit(False)
+        print(f"[{time.time() - t0:6.1f} s] audit while running: {au['kangaroos']} kangaroos re-derived from their distances, "
+              f"{au['kangaroo_mismatches']} mismatches ({au['herd_ms']:.1f} ms on the device, {au['seconds'] * 1e3:.0f} ms pause)", flush=True)
+        next_audit += a.audit_every
 
     print(f"[{time.time() - t0:6.1f} s] {st['jumps'] / max(st['seconds'], 1e-9) / 1e6:9.1f} MK/s  count 2^{math.log2(max(st['jumps'], 1)):.2f}  "
           f"DPs 2^{math.log2(max(st['dps'], 1)):.2f}  replaced {st['same_herd']}  lost {st['dps_lost']}", flush=True)
 if a.save:
     s.save(a.save, True)
+if not a.no_audit:
+    # whole-run audit (kngs_audit): a walk error is permanent for its kangaroo, so a clean herd after J jumps certifies all J;
+    # the table half re-derives every stored distinguished point the way the reference's -wcheck does (Check.cpp:141-411)
+    au = s.audit(True)
+    st = s.stats()
+    print(f"AUDIT after 2^{math.log2(max(st['jumps'], 1)):.2f} jumps: {au['kangaroos']} kangaroos (x and y) and {au['table_points']} table entries "
+          f"re-derived from their distances on the device: {au['kangaroo_mismatches']} + {au['table_mismatches']} mismatches; "
+          f"{st['same_herd']} kangaroos had been replaced on the way; device {au['herd_ms']:.1f} + {au['table_ms']:.1f} ms, wall {au['seconds']:.2f} s", flush=True)
 s.stop()
 st = s.stats()
 if rc == 1:
