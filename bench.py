@@ -587,11 +587,11 @@ def main():
             from kangaroo_amd import solver as sv
 
             s = sv.Solver(RANGE_START, RANGE_START + (1 << RANGE_POWER) - 1, (kx, ky), gpus=(local_rank,), grid=(gx, gy), dp=dp,
-                          seed=0x5EED, max_launches=max(100, args.steps))  # ~2 s: long enough for the clock governor to settle
+                          seed=0x5EED, max_launches=max(400, args.steps))  # ~9 s: the sustained figure (clock governor settled), 2^38.6 jumps audited
             s.prepare()
             sampler = GpuSampler([dev], hz=50.0).start()
             s.start()
-            s.wait(120)
+            s.wait(180)
             sustained = sampler.stop().summary()
             st = s.stats()
             # whole-run audit on the device: every kangaroo and every table entry re-derived from its distance (kngs_audit)

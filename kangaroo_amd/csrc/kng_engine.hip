@@ -81,9 +81,6 @@ static_assert(sizeof(WalkAsmArgs) == 96 && offsetof(WalkAsmArgs, dp_mask) == 0x4
 // The herd state (x, y, d) streams: every vector is read once and written once per jump and not touched again for a
 // whole pass (~0.4 ms, ~1 GB of traffic later).  Non-temporal accesses ("nt": stream through L2 without
 // displacing anything worth keeping) are worth +1.9 % on the walk (profiles/r01_ab_nontemporal.txt).
-#ifndef KNG_WARM_L2
-#define KNG_WARM_L2 0 // measured in round 4: see profiles/r04_ab_warm_l2.txt
-#endif
 #ifndef KNG_NT_LOAD
 #define KNG_NT_LOAD 1
 #endif
@@ -315,23 +312,10 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
                 const v16 b0 = xch[(2 * slot) * 64 + col], b1 = xch[(2 * slot + 1) * 64 + col];
                 return fe{{b0.x, b0.y, b1.x, b1.y}};
             };
-#if KNG_WARM_L2
-            // The coming pass starts where this one ended: pull the first kangaroo's lines (x, y, low distance word, and the
-            // product behind it) into L2 now, so that the loop's first loads -- issued behind four barriers and an
-            // inversion -- do not start from HBM.  One dword per lane touches the whole 16-byte vector's line.
-            if (G) {
-                const bool bw = !(step & 1);
-                const size_t i0 = (size_t)(bw ? (G - 1) : 0) * L + t, i1 = (size_t)(bw ? (G > 1 ? G - 2 : 0) : (G > 1 ? 1 : 0)) * L + t;
-                uint32_t sink = *reinterpret_cast<const volatile uint32_t *>(a.x01 + i0);
-                sink |= *reinterpret_cast<const volatile uint32_t *>(a.x23 + i0);
-                sink |= *reinterpret_cast<const volatile uint32_t *>(a.y01 + i0);
-                sink |= *reinterpret_cast<const volatile uint32_t *>(a.y23 + i0);
-                sink |= *reinterpret_cast<const volatile uint32_t *>(dlo + i0);
-                sink |= *reinterpret_cast<const volatile uint32_t *>(a.s01 + i1);
-                sink |= *reinterpret_cast<const volatile uint32_t *>(a.s23 + i1);
-                asm volatile("" ::"v"(sink));
-            }
-#endif
+            // (Round 4 measured two variations here and kept neither: loading the coming pass's first kangaroo before these
+            // barriers so that its lines wait in L2 -- -0.6 % when consumed at once, +-0 when consumed behind the inversion --
+            // and two 256-thread blocks per CU with one tree level each, so that one block's inversion overlaps the other's
+            // walking -- -3.4 %, -1.5 % with a rotating root wave.  profiles/r04_ab_warm_l2.txt, profiles/r04_ab_kernel.txt.)
             if (w >= 4) put(w, acc);
             __syncthreads();
             fe pb = fe_one(), pre = fe_one(), i = fe_one();
