@@ -352,7 +352,7 @@ def bench_multi(args, ranks, n_gpus):
         for g in range(n_gpus):
             gs = s.gpu_stats(g)
             kms = gs["kernel_ms_sum"] / max(1, gs["launches"])
-            per_gpu.append({"gpu": g, "device": devices[g], "launches": gs["launches"], "kernel_ms": round(kms, 3),
+            per_gpu.append({"gpu": g, "device": devices[g], "numa_node": s.gpu_option(g, "numa_node"), "launches": gs["launches"], "kernel_ms": round(kms, 3),
                             "kernel_rate": round(gs["kangaroos"] * k.KNG_NB_RUN / (kms * 1e-3) / 1e6, 1)})
         load = s.consumer_load()
         host = s.host_stats()  # is the host keeping up?  (the threads are still alive: the kernel-side sums come after stop)

@@ -58,6 +58,9 @@ int kng_device_count(void);
 /* name (<= name_cap bytes incl. NUL), compute units, total memory, gcn arch string */
 int kng_device_info(int dev, char *name, size_t name_cap, int *cu_count, uint64_t *mem_bytes,
                     char *arch, size_t arch_cap);
+/* NUMA node of the host the device hangs off (sysfs numa_node of its PCI address), or -1 when unknown: a host that drives
+ * several GPUs (Kangaroo.cpp:1041-1047, one thread per GPU) keeps each GPU's thread and its pinned DP buffers on that node */
+int kng_device_numa_node(int dev);
 /* free / total device memory right now (hipMemGetInfo): lets a host that re-creates its engine once per key
  * (Kangaroo.cpp:1021-1075, ctor :523, `delete gpu` :634) check that a create / destroy cycle gives everything back */
 int kng_device_free_bytes(int dev, uint64_t *free_bytes, uint64_t *total_bytes);

@@ -908,6 +908,22 @@ int kng_device_info(int dev, char *name, size_t name_cap, int *cu_count, uint64_
     return KNG_OK;
 }
 
+int kng_device_numa_node(int dev) {
+    if (dev < 0 || dev >= kng_device_count()) return -1;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, dev) != hipSuccess) return -1;
+    for (char *c = bdf; *c; c++)
+        if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a'); // sysfs spells the address in lower case
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
 int kng_device_free_bytes(int dev, uint64_t *free_bytes, uint64_t *total_bytes) {
     if (dev < 0 || dev >= kng_device_count()) return fail(KNG_E_NODEVICE, "invalid device %d", dev);
     HIP_TRY(hipSetDevice(dev));

@@ -179,6 +179,9 @@ struct Worker {
     std::atomic<uint64_t> host_us_sum{0}, host_us_max{0}, ingest_us_max{0}, late{0};
     bool ended = false, paused = false; // guarded by kngs_solver::ctl_m
     uint64_t reset_seq = 0;
+    bool pin = false;  // confine this GPU's host thread to the NUMA node its device hangs off (kngs_prepare)
+    cpu_set_t cpus;
+    int numa_node = -1;
     std::vector<Chunk *> out; // per-consumer chunk being filled by ingest()
     std::vector<DpMsg> stage;    // per-consumer staging groups of ingest() (software write-combining)
     std::vector<uint8_t> staged; // messages waiting in each group
@@ -526,6 +529,7 @@ void worker_main(kngs_solver *s, Worker *w) {
         s->ctl_cv.notify_all();
     };
 
+    if (w->pin) (void)sched_setaffinity(0, sizeof w->cpus, &w->cpus); // next to its GPU: the ring it reads was written over that node's PCIe root
     if (kng_launch(w->eng) != KNG_OK) return bail(std::string("kng_launch: ") + kng_last_error());
     Clock::time_point host_t0{};
     bool have_host_t0 = false;
@@ -893,8 +897,21 @@ int kngs_prepare(kngs_solver *s) {
         }
         if (mf > s->cfg.max_found) s->cfg.max_found = mf; // one drain buffer size for every worker
     }
+    const std::vector<cpu_set_t> nodes = (cfg.flags & KNGS_FLAG_NO_PIN) ? std::vector<cpu_set_t>() : numa_node_cpus();
     for (Worker *w : s->workers) {
-        if (kng_create(w->dev, w->grid_x, w->grid_y, s->cfg.max_found, &w->eng) != KNG_OK)
+        // The engine's pinned buffers (the DP rings the kernel writes over PCIe) are placed by the allocating thread's node:
+        // create the engine from the node its device hangs off, and keep the GPU's host thread there (worker_main).
+        cpu_set_t before;
+        bool moved = false;
+        w->numa_node = kng_device_numa_node(w->dev);
+        if (nodes.size() > 1 && w->numa_node >= 0 && (size_t)w->numa_node < nodes.size() && sched_getaffinity(0, sizeof before, &before) == 0) {
+            w->pin = true;
+            w->cpus = nodes[(size_t)w->numa_node];
+            moved = sched_setaffinity(0, sizeof w->cpus, &w->cpus) == 0;
+        }
+        const int crc = kng_create(w->dev, w->grid_x, w->grid_y, s->cfg.max_found, &w->eng);
+        if (moved) (void)sched_setaffinity(0, sizeof before, &before);
+        if (crc != KNG_OK)
             return undo(fail("kng_create(gpu %d): %s", w->dev, kng_last_error()));
         if (kng_set_params(w->eng, s->dp_mask, s->jd, s->jx, s->jy) != KNG_OK) return undo(fail("kng_set_params: %s", kng_last_error()));
         // FetchWalks (Kangaroo.cpp:646-668): take what the file still holds, create the rest
@@ -1009,6 +1026,10 @@ int kngs_gpu_option(const kngs_solver *s, int gpu, const char *key, int64_t *val
     if (gpu < 0 || (size_t)gpu >= s->workers.size()) return fail("no gpu %d", gpu);
     const Worker *w = s->workers[(size_t)gpu];
     if (!w->eng) return fail("gpu %d has no engine yet (kngs_prepare)", gpu);
+    if (std::strcmp(key, "numa_node") == 0) { // where this GPU's host thread and pinned buffers were placed (-1: not placed)
+        *value = w->pin ? w->numa_node : -1;
+        return 0;
+    }
     if (kng_get_option(w->eng, key, value) != KNG_OK) return fail("%s", kng_last_error());
     return 0;
 }
