@@ -16,7 +16,7 @@ if [ -x oracle/_ref/kangaroo_hip ]; then
 fi
 echo "== bench"; python bench.py 2> $OUT/${TAG}_bench.err | tee $OUT/${TAG}_bench.json; tail -3 $OUT/${TAG}_bench.err
 echo "== bench --gpus 2 on this one device is not possible; host path at the 8-GPU DP rate instead"
-[ -x tools/dp_ingest_bench ] && ./tools/dp_ingest_bench --feeders 8 --launches 40 --launch-ms 25 | tee $OUT/${TAG}_dp_ingest.txt
+[ -x tools/dp_ingest_bench ] && (./tools/dp_ingest_bench --feeders 8 --launches 60 --launch-ms 21; ./tools/dp_ingest_bench --feeders 8 --launches 60) | tee $OUT/${TAG}_dp_ingest.txt
 echo "== rocprofv3 kernel trace"
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o kt -- python $OLDPWD/bench.py --no-cpu-baseline --no-pipeline --no-secondary > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err)
 find $OUT/${TAG}_prof -name "*kernel_stats*" | head -3
