@@ -40,6 +40,13 @@ int main(int argc, char **argv) {
     if (kngs_stop(s) != 0) return fail("kngs_stop", kngs_last_error());
     kngs_stats st;
     kngs_get_stats(s, &st);
+    // whole-run audit through the C ABI: every kangaroo and every table entry re-derived from its distance on the device
+    kngs_audit_result au;
+    if (kngs_audit(s, 1, &au) != 0) return fail("kngs_audit", kngs_last_error());
+    if (au.kangaroos != st.kangaroos || au.kangaroo_mismatches != 0 || au.table_points != st.table_items || au.table_mismatches != 0)
+        return fail("kngs_audit", "mismatches, or not everything was audited");
+    kngs_host_stats_t hs;
+    if (kngs_host_stats(s, &hs) != 0 || hs.consumers < 1 || hs.effective_cpus < 1.0) return fail("kngs_host_stats", kngs_last_error());
     if (kngs_save(s, path, 1) != 0) return fail("kngs_save", kngs_last_error());
     kngs_destroy(s);
 
@@ -53,7 +60,7 @@ int main(int argc, char **argv) {
         kngt_count(t) != st.table_items || std::memcmp(h.key_x, cfg.key_x, 32) != 0)
         return fail("work file", "header or counters differ from the solver's statistics");
     kngt_destroy(t);
-    std::printf("CPP solver ok: key 0x%" PRIX64 " after %" PRIu64 " launches, %" PRIu64 " DPs, %" PRIu64 " kangaroos saved\n", priv[0],
-                st.launches, st.dps, n);
+    std::printf("CPP solver ok: key 0x%" PRIX64 " after %" PRIu64 " launches, %" PRIu64 " DPs, %" PRIu64 " kangaroos saved; audit: %" PRIu64
+                " kangaroos + %" PRIu64 " table entries clean\n", priv[0], st.launches, st.dps, n, au.kangaroos, au.table_points);
     return 0;
 }
