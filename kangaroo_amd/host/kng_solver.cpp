@@ -740,7 +740,7 @@ double effective_cpus();
 void start_consumers(kngs_solver *s, int nc) {
     for (int c = 0; c < nc; c++) s->consumers.push_back(new Consumer());
     const std::vector<cpu_set_t> nodes = (s->cfg.flags & KNGS_FLAG_NO_PIN) ? std::vector<cpu_set_t>() : numa_node_cpus();
-    if (nodes.size() > 1) {
+    if (!nodes.empty()) {
         // one physical core per consumer, spread evenly over the node's cores (hence over its L3 slices): left to itself the
         // scheduler wakes a table thread next to the GPU thread that fed it, and a dozen of them end up sharing a few cores
         // and one L3 while the rest of the socket idles (profiles/r04_dp_host_bigregions.txt: 16 threads 159 M points/s,
@@ -755,11 +755,14 @@ void start_consumers(kngs_solver *s, int nc) {
             for (size_t j = 0; j < mine.size(); j++) {
                 Consumer *cs = s->consumers[(size_t)mine[j]];
                 cs->pin = true;
-                if (cores.size() >= mine.size()) {
+                // (a single-node machine is pinned too -- the crowding has nothing to do with NUMA -- but only where cores abound)
+                if (cores.size() >= mine.size() * (nodes.size() > 1 ? 1 : 2)) {
                     CPU_ZERO(&cs->cpus);
                     CPU_SET(cores[j * cores.size() / mine.size()], &cs->cpus);
-                } else {
+                } else if (nodes.size() > 1) {
                     cs->cpus = nodes[nd];
+                } else {
+                    cs->pin = false;
                 }
             }
         }
