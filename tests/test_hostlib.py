@@ -86,3 +86,36 @@ def test_point_add(hl, orc):
     assert hl.point_add((gx, gy), (gx, gy)) == (0, x2, y2)  # doubling
     assert hl.point_add((gx, gy), (x2, y2)) == (0, x3, y3)
     assert hl.point_add((gx, gy), (gx, P - gy))[0] == -1  # P + (-P) = infinity
+
+
+def test_telemetry_degrades_to_unavailable_without_a_device():
+    """kangaroo_amd/telemetry.py (package power / GFX clock for the bench line) must never raise: on a box without an
+    AMD GPU it reports itself unavailable, with a reason, and the sampler still measures its window."""
+    import time
+
+    from kangaroo_amd.telemetry import GpuSampler, power_cap_w
+
+    with GpuSampler([0], hz=100.0) as s:
+        time.sleep(0.05)
+    out = s.summary()
+    assert isinstance(out, dict) and "available" in out
+    if not out["available"]:
+        assert out["reason"] and power_cap_w(0) is None
+    else:  # a GPU box: the fields the bench line carries
+        dev = out["devices"][0]
+        assert dev["device"] == 0 and out["window_s"] >= 0.05 and dev["power_cap_w"]
+
+
+def test_bench_power_bound_arithmetic():
+    """bench.py's second bound: (P_cap - P_static) / E_dyn_per_jump from the recorded instruction and byte energies."""
+    import bench
+
+    fake = {"available": True, "devices": [{"device": 0, "power_cap_w": 1400.0, "power_w": {"median": 1360.0}}]}
+    pb = bench._power_bound(fake, 208.0, 25000.0)
+    e_dyn = (410 * 1.38 + 475 * 0.75 + 140 * 0.36) / 64 + 208.0 * 0.1
+    assert abs(pb["e_dyn_nj_per_jump"] - e_dyn) < 0.01
+    assert abs(pb["value_mks"] - (1400.0 - 342.0) / (e_dyn * 1e-9) / 1e6) < 1.0
+    assert abs(pb["measured_nj_per_jump"] - 1360.0 / 25000e6 * 1e9) < 0.01
+    assert 0.8 < pb["frac_of_bound_at_measured_power"] < 1.0
+    assert "value_mks" not in bench._power_bound({"available": False}, 208.0, 25000.0)
+    assert bench.effective_cpus() >= 1.0
