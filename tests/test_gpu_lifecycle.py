@@ -87,8 +87,9 @@ def test_200_create_destroy_cycles_give_the_memory_back(kng):
         if i % 20 == 0:
             frees.append(kng.device_free_bytes(0)[0])
     dt = time.time() - t0
-    assert frees[-1] == free0, (free0, frees)
-    assert max(frees) - min(frees) == 0, frees
+    # (a cycle holds ~0.95 GB: one leaked cycle would show as hundreds of MiB; the allowance is for the runtime's own pools)
+    assert abs(frees[-1] - free0) <= (8 << 20), (free0, frees)
+    assert max(frees) - min(frees) <= (8 << 20), frees
     print(f"\n200 create/destroy cycles at {gx}x{gy}x128 kangaroos: {1000 * dt / 200:.1f} ms per cycle, free device memory "
           f"{free0 / 2**30:.2f} GiB of {total / 2**30:.2f} GiB before and after")
 

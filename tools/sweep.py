@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--blocks", default="64,256")
     ap.add_argument("--launches", type=int, default=3)
     ap.add_argument("--dp", type=int, default=14)
-    ap.add_argument("--shares", default="8", help="comma list of 1/8: waves of a block sharing one inversion")
+    ap.add_argument("--shares", default="8", help="waves of a block sharing one inversion: 8 (the only form left since round 4)")
     ap.add_argument("--dsplit", type=int, default=-1, help="-1 auto / 0 / 1: low-word streaming of the distances")
     ap.add_argument("--jd-bits", type=int, default=40, help="size of the synthetic jump distances: 54+ makes both distance words stream (the non-dsplit kernels)")
     ap.add_argument("--lanes", default="", help="explicit lane counts (ragged groups); overrides --groups")
