@@ -109,9 +109,9 @@ def test_only_the_dp_buffers_of_the_mode_in_use_are_allocated(kng):
     assert eng.GetMemory() >= 2 * max_found * 64
     assert copy_mode >= 2 * max_found * 64
     eng.set_option("dp_ring", 1)
-    assert before - kng.device_free_bytes(0)[0] == ring_mode
+    assert abs((before - kng.device_free_bytes(0)[0]) - ring_mode) <= (8 << 20)
     eng.close()
-    assert kng.device_free_bytes(0)[0] == before
+    assert abs(kng.device_free_bytes(0)[0] - before) <= (8 << 20)
 
 
 def test_switching_dp_ring_with_points_waiting_is_refused(kng):
