@@ -527,7 +527,7 @@ def main():
         if i:
             counts["dps"] += len(eng.drain(raw=True))
             counts["lost"] += eng.lastLost
-        eng.wait()
+        eng.wait(spin=True)  # GPUEngine::Launch's spinWait (GPUEngine.cu:621-629): no wake-up latency between launches
         kernel_ms.append(eng.last_kernel_ms())
         counts["exits"] = counts.get("exits", 0) + eng.get_option("exact_exits")
 
