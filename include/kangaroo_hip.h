@@ -73,6 +73,13 @@ int kng_default_grid(int dev, int *x, int *y);
 int kng_create(int dev, int grid_x, int grid_y, uint32_t max_found, kng_engine **out);
 void kng_destroy(kng_engine *h); /* safe while a launch is in flight (Kangaroo.cpp:572-634) */
 
+/* Raise the DP capacity per launch to at least `points` (never lowers it).  The reference fixes max_found in the program
+ * (65536*2, Kangaroo.cpp:523) for a V100-sized herd; at the MI355X default grid and the DP size the program suggests for
+ * eight GPUs one launch yields 262 144 points, of which that constant would drop half (GPUEngine.cu:641-648).  The class
+ * shim calls this from SetParams with twice the expected yield of herd and mask.  Only between launches (nothing
+ * outstanding, nothing undrained): KNG_E_STATE otherwise, capacity unchanged.  "max_found" reads the capacity back. */
+int kng_reserve_points(kng_engine *h, uint32_t points);
+
 uint64_t kng_nb_kangaroos(const kng_engine *h); /* GetNbThread()*GetGroupSize(), GPUEngine.cu:377 */
 uint64_t kng_memory_bytes(const kng_engine *h); /* GetMemory(), GPUEngine.cu:266-268 (64-bit)  */
 
@@ -123,6 +130,8 @@ int kng_set_kangaroo(kng_engine *h, uint64_t kidx, const uint64_t x[4], const ui
 int kng_launch(kng_engine *h);
 /* 1 when a launch has been started and not yet waited for, else 0 */
 int kng_outstanding(const kng_engine *h);
+/* 1 when a waited launch still has its points in the engine (kng_drain / kng_drain_view not yet called), else 0 */
+int kng_undrained(const kng_engine *h);
 /* block until the outstanding launch has finished.  spin != 0 busy-waits, otherwise the host
  * thread sleeps on the completion event (the reference polls with 1 ms sleeps, :621-629). */
 int kng_wait(kng_engine *h, int spin);

@@ -1111,6 +1111,27 @@ int kng_set_option(kng_engine *h, const char *key, int64_t value) {
     return KNG_OK;
 }
 
+int kng_reserve_points(kng_engine *h, uint32_t points) {
+    if (!h) return fail(KNG_E_ARG, "null engine");
+    if (points <= h->max_found) return KNG_OK;
+    if (h->outstanding || h->slot_ready >= 0) return fail(KNG_E_STATE, "kng_reserve_points: a launch is outstanding or its points have not been drained");
+    if (h->use_asm && points > (1u << 26)) return fail(KNG_E_ARG, "the scheduled loop addresses at most 2^26 DP records");
+    HIP_TRY(hipSetDevice(h->dev));
+    const uint32_t before = h->max_found;
+    free_dp_buffers(h, h->dp_ring != 0);
+    h->view = nullptr;
+    h->max_found = points;
+    if (int rc = alloc_dp_buffers(h)) {
+        free_dp_buffers(h, h->dp_ring != 0);
+        h->max_found = before;
+        if (alloc_dp_buffers(h) != KNG_OK) h->have_params = false; // no landing buffers at all: refuse to launch
+        return rc;
+    }
+    h->bytes = 7 * (uint64_t)h->n * sizeof(v16) + JT_WORDS * 8 + 2 * 64 + (h->dp_ring ? 0 : 2 * (uint64_t)h->max_found * sizeof(DpRecord));
+    if (h->have_params) return upload_loop_args(h);
+    return KNG_OK;
+}
+
 int kng_get_option(const kng_engine *h, const char *key, int64_t *value) {
     if (!h || !key || !value) return fail(KNG_E_ARG, "null argument");
     std::string k(key);
@@ -1124,6 +1145,7 @@ int kng_get_option(const kng_engine *h, const char *key, int64_t *value) {
     else if (k == "dsplit") *value = h->dsplit_on ? 1 : 0;
     else if (k == "exact_exits") *value = h->last_exact_exits;
     else if (k == "cu_count") *value = h->cu_count;
+    else if (k == "max_found") *value = h->max_found;
     else if (k == "audit_us") *value = (int64_t)(h->last_audit_ms * 1000.0f + 0.5f);
     else if (k == "waves_per_cu") *value = h->cu_count ? (int64_t)((h->lanes / 64 + h->cu_count - 1) / h->cu_count) : 0;
     else return fail(KNG_E_ARG, "unknown option '%s'", key);
@@ -1380,7 +1402,9 @@ int kng_launch(kng_engine *h) {
     a.n_kang = h->n;
     a.nsteps = h->nsteps;
     a.resume = h->products_valid ? 1 : 0;
-    h->products_valid = (h->nsteps % 2) == 0; // this launch leaves them in ascending order when its passes pair up
+    // Whatever fails from here on, the S planes can no longer be trusted to hold the products of the state the next launch
+    // starts from: the flag is raised again only once this launch is known to be queued.
+    h->products_valid = false;
     a.asm_args = (uint64_t)(h->asm_args + s);
     HIP_TRY(hipMemsetAsync(h->dp_count[s], 0, 8, h->walk)); // GPUEngine.cu:543 (+ the launch's exact-path exit counter)
     HIP_TRY(hipEventRecord(h->ev_start[s], h->walk));
@@ -1397,10 +1421,12 @@ int kng_launch(kng_engine *h) {
     HIP_TRY(hipMemcpyAsync(h->h_count[s], h->dp_count[s], 8, hipMemcpyDeviceToHost, h->walk));
     HIP_TRY(hipEventRecord(h->ev_done[s], h->walk));
     h->outstanding = true;
+    h->products_valid = (h->nsteps % 2) == 0; // this launch leaves them in ascending order when its passes pair up
     return KNG_OK;
 }
 
 int kng_outstanding(const kng_engine *h) { return (h && h->outstanding) ? 1 : 0; }
+int kng_undrained(const kng_engine *h) { return (h && h->slot_ready >= 0) ? 1 : 0; }
 
 void *kng_alloc_pinned(size_t size) {
     void *p = nullptr;

@@ -25,6 +25,37 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <utility>
+
+// The C handle behind a GPUEngine object, for hosts that drive the hot loop through the C ABI (SolveKeyGPU_kng.cpp: kng_wait /
+// kng_launch / kng_drain_view instead of Launch's per-item copies) while leaving construction, SetParams, Set/GetKangaroos and
+// SetKangaroo to the class.  The reference's header has no accessor to add one to, so the objects are kept in a small list.
+static std::mutex g_engines_lock;
+static std::vector<std::pair<GPUEngine *, kng_engine *>> g_engines;
+static void remember_engine(GPUEngine *g, kng_engine *h) {
+  std::lock_guard<std::mutex> l(g_engines_lock);
+  for (auto &e : g_engines)
+    if (e.first == g) {
+      e.second = h;
+      return;
+    }
+  g_engines.emplace_back(g, h);
+}
+static void forget_engine(GPUEngine *g) {
+  std::lock_guard<std::mutex> l(g_engines_lock);
+  for (size_t i = 0; i < g_engines.size(); i++)
+    if (g_engines[i].first == g) {
+      g_engines.erase(g_engines.begin() + (long)i);
+      return;
+    }
+}
+extern "C" kng_engine *kng_shim_engine(GPUEngine *g) {
+  std::lock_guard<std::mutex> l(g_engines_lock);
+  for (auto &e : g_engines)
+    if (e.first == g) return e.second;
+  return NULL;
+}
 
 static const size_t INT_STRIDE = sizeof(Int) / sizeof(uint64_t);
 
@@ -76,9 +107,11 @@ GPUEngine::GPUEngine(int nbThreadGroup, int nbThreadPerGroup, int gpuId, uint32_
   snprintf(tmp, sizeof tmp, "GPU #%d %s (%dx%d cores) Grid(%dx%d)", gpuId, name, cu, 64, nbThreadGroup, nbThreadPerGroup);
   deviceName = std::string(tmp);
   initialised = true;
+  remember_engine(this, h);
 }
 
 GPUEngine::~GPUEngine() {
+  forget_engine(this);
   kng_destroy(ENGINE); // waits for an in-flight kernel (Kangaroo.cpp:572-634 deletes mid-flight)
   ENGINE = NULL;
   kng_free_pinned(ITEMBUF);
@@ -137,7 +170,32 @@ void GPUEngine::SetParams(uint64_t dpMask, Int *distance, Int *px, Int *py) {
     memcpy(jx[i], px[i].bits64, 32);
     memcpy(jy[i], py[i].bits64, 32);
   }
-  (void)KNG_MUST(kng_set_params(ENGINE, dpMask, &jd[0][0], &jx[0][0], &jy[0][0]), "SetParams");
+  if (!KNG_MUST(kng_set_params(ENGINE, dpMask, &jd[0][0], &jx[0][0], &jy[0][0]), "SetParams")) return;
+  // `maxFound` is a floor, not a ceiling.  The program passes a constant sized for a V100 herd (65536*2, Kangaroo.cpp:523;
+  // 65536 in Check.cpp:470).  The herd and the mask say what a launch will really yield: herd x NB_RUN jumps, one in
+  // 2^(bits of the mask) distinguished.  At the MI355X default grid (2^23 kangaroos) and the DP size the program suggests for
+  // eight GPUs (11) that is 262 144 points per launch -- the constant would drop half of them, every launch, with one
+  // "items lost" warning (GPUEngine.cu:641-648).  Capacity = max(maxFound, 2 x expected + 4096); the rings of the engine and
+  // this object's landing buffer grow accordingly.  Only possible between launches: a SetParams that arrives while a kernel
+  // runs (allowed, see kng_set_params) keeps the capacity it has.
+  int bits = 0;
+  for (uint64_t m = dpMask; m; m &= m - 1) bits++;
+  const uint64_t herd = kng_nb_kangaroos(ENGINE);
+  const uint64_t expected = bits >= 64 ? 0 : (herd * KNG_NB_RUN) >> bits;
+  uint64_t want = 2 * expected + 4096;
+  if (want > (1ULL << 26)) want = 1ULL << 26; // what the scheduled loop can address; beyond it the mask is the caller's problem
+  if (want > maxFound && !kng_outstanding(ENGINE) && !kng_undrained(ENGINE)) {
+    kng_item *bigger = (kng_item *)kng_alloc_pinned((size_t)want * sizeof(kng_item));
+    if (bigger && kng_reserve_points(ENGINE, (uint32_t)want) == KNG_OK) {
+      kng_free_pinned(ITEMBUF);
+      ITEMBUF = bigger;
+      maxFound = (uint32_t)want;
+    } else {
+      fprintf(stderr, "GPUEngine: SetParams: could not raise the DP capacity to %llu points per launch (%s); keeping %u\n",
+              (unsigned long long)want, kng_last_error(), maxFound);
+      kng_free_pinned(bigger);
+    }
+  }
 }
 
 void GPUEngine::SetKangaroos(Int *px, Int *py, Int *d) {

@@ -8,16 +8,11 @@
 // more than 32 entries per fine array (a local re-split by the one thread that owns the bucket).  An insertion then
 // moves ~0.3 KB whatever the size of the table; the serialised form is unchanged.
 //
-// Memory.  Dozens of consumer threads growing small arrays through malloc, in one address space that gains gigabytes
-// per second, serialise on the kernel's mmap lock (heap growth + page faults): measured on the 256-thread GPU host,
-// 16 consumers inserted 30 M points/s and 96 consumers 11 M (profiles/r02_dp_ingest_*.txt).  The table therefore owns
-// its memory: every bucket belongs to one of 64 arenas (by a scramble of its index, the same one the solver uses to
-// assign buckets to consumers, so an arena is shared by at most two threads; a spin lock covers that), an arena
-// takes regions of 64 KiB doubling to 2 MiB from the OS (huge pages where the system grants them), carves blocks of 64, 96, 128, 192, ... bytes from them and
-// recycles freed blocks through per-size free lists.  Nothing goes back to the OS before kngt_reset.
+// Memory.  The table owns its memory (kng_arena.h says why): every bucket belongs to one of 64 arenas (by a scramble of its
+// index, the same one the solver uses to assign buckets to consumers, so an arena is shared by at most two threads; a spin
+// lock covers that).  Nothing goes back to the OS before kngt_reset.
 #include "kng_dptable.h"
 
-#include <sys/mman.h>
 #include <sys/stat.h>
 
 #include <atomic>
@@ -28,6 +23,7 @@
 #include <new>
 #include <vector>
 
+#include "kng_arena.h"
 #include "kng_host.h"
 
 namespace {
@@ -37,89 +33,8 @@ struct Fine {
     uint32_t n = 0, cap = 0;
 };
 
-// ---- arena allocator: size classes 64, 96, 128, 192, 256, 384, ... bytes (class c: 64 << c/2, times 1.5 when c is odd) ----
-// 64 B .. 1 GiB.  Blocks above REGION get a mapping of their own (arena_alloc: want = sz): a skewed bucket -- one run with
-// more than 131 072 entries, or the 2^k run headers of a bucket split 2^20 ways and beyond -- must not end as "out of memory"
-// while memory is there.
-constexpr int MIN_CLASS = 0, MAX_CLASS = 48;
-constexpr size_t REGION_MIN = (size_t)64 << 10;       // an arena's first region; each further one doubles ...
-constexpr int REGION_DOUBLINGS = 12;                  // ... up to 256 MiB (a small table must not cost N_ARENAS x 2 MiB).
-// Large regions on purpose: address space is free (pages arrive on first touch), but every mmap takes the process's mm lock
-// for writing and has to wait for the page faults in flight on the neighbouring mapping it merges with -- huge-page faults
-// that clear 2 MiB each.  With 2 MiB regions the table threads of an 8-GPU run issued ~4000 mmaps per second and spent two
-// thirds of their time blocked behind one another (profiles/r04_dp_probe.txt: 16 consumers 138 M points/s, 32 consumers 117).
+using namespace kng_arena;
 constexpr unsigned ARENA_BITS = 6, N_ARENAS = 1u << ARENA_BITS;
-
-inline size_t class_bytes(int c) { return ((size_t)(c & 1 ? 96 : 64)) << (c >> 1); }
-
-struct Arena {
-    std::atomic_flag lock = ATOMIC_FLAG_INIT;
-    char *cur = nullptr, *end = nullptr;              // bump area of the current region
-    void *free_list[MAX_CLASS + 1] = {};
-    std::vector<std::pair<void *, size_t>> regions;   // for munmap
-    uint64_t bytes = 0;                               // taken from the OS
-};
-
-inline int class_of(size_t bytes) {
-    int c = MIN_CLASS;
-    while (class_bytes(c) < bytes) c++;
-    return c;
-}
-
-struct Locked {
-    Arena &a;
-    explicit Locked(Arena &ar) : a(ar) {
-        while (a.lock.test_and_set(std::memory_order_acquire)) {
-        }
-    }
-    ~Locked() { a.lock.clear(std::memory_order_release); }
-};
-
-void *arena_alloc(Arena &a, int c) {
-    if (c > MAX_CLASS) return nullptr;
-    Locked g(a);
-    if (void *p = a.free_list[c]) {
-        a.free_list[c] = *static_cast<void **>(p);
-        return p;
-    }
-    const size_t sz = class_bytes(c);
-    if ((size_t)(a.end - a.cur) < sz) {
-        // the tail of the old region is recycled as smaller blocks
-        for (int k = MAX_CLASS; k >= MIN_CLASS; k--)
-            while ((size_t)(a.end - a.cur) >= class_bytes(k)) {
-                *reinterpret_cast<void **>(a.cur) = a.free_list[k];
-                a.free_list[k] = a.cur;
-                a.cur += class_bytes(k);
-            }
-        size_t want = REGION_MIN << (a.regions.size() < (size_t)REGION_DOUBLINGS ? a.regions.size() : (size_t)REGION_DOUBLINGS);
-        if (want < sz) want = sz;
-        void *m = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-        if (m == MAP_FAILED) return nullptr;
-        if (want >= ((size_t)2 << 20)) (void)madvise(m, want, MADV_HUGEPAGE);
-        a.regions.emplace_back(m, want);
-        a.bytes += want;
-        a.cur = static_cast<char *>(m);
-        a.end = a.cur + want;
-    }
-    void *p = a.cur;
-    a.cur += sz;
-    return p;
-}
-
-void arena_free(Arena &a, void *p, int c) {
-    if (!p) return;
-    Locked g(a);
-    *static_cast<void **>(p) = a.free_list[c];
-    a.free_list[c] = p;
-}
-
-void arena_release(Arena &a) {
-    for (auto &r : a.regions) munmap(r.first, r.second);
-    a.regions.clear();
-    a.cur = a.end = nullptr;
-    for (void *&f : a.free_list) f = nullptr;
-    a.bytes = 0;
-}
 
 struct Bucket {
     Fine *fine = nullptr; // 1 << k arrays, ordered by the top k bits of x[1]
@@ -135,7 +50,12 @@ constexpr uint64_t D_SIGN = 1ULL << 63, D_TYPE = 1ULL << 62;
 // 32 (runs of 8..32): at 60-80 M entries an insertion cost 68-72 ns against 53-61 ns with 8, and 60 against 45 bytes of memory
 // per entry (less slack in short runs outweighs more 16-byte run headers); 16 table threads took 150 -> 182 M points/s
 // (profiles/r04_dp_probe_split.txt).  KNGT_SPLIT_AVG overrides it for measurements.
-static const uint32_t SPLIT_AVG = getenv("KNGT_SPLIT_AVG") ? (uint32_t)atoi(getenv("KNGT_SPLIT_AVG")) : 8;
+static uint32_t split_avg_knob() {
+    const char *e = getenv("KNGT_SPLIT_AVG");
+    const long v = e ? atol(e) : 8;
+    return (uint32_t)(v < 2 ? 2 : v > 4096 ? 4096 : v); // k_for() halves it: below 2 every bucket would split without end
+}
+static const uint32_t SPLIT_AVG = split_avg_knob();
 static const bool GROW2 = getenv("KNGT_GROW2") && atoi(getenv("KNGT_GROW2")); // runs grow by doubling instead of by size class (measurement knob)
 constexpr uint8_t K_MAX = 24;
 
@@ -404,7 +324,7 @@ uint64_t kngt_serialised_size(const kngt_table *t) { return (uint64_t)KNGT_BUCKE
 
 uint64_t kngt_memory_bytes(const kngt_table *t) {
     uint64_t m = sizeof(kngt_table);
-    for (const Arena &a : t->arena) m += a.bytes - (uint64_t)(a.end - a.cur); // mapped less the untouched tail of the current region
+    for (const Arena &a : t->arena) m += arena_touched(a);
     return m;
 }
 

@@ -12,10 +12,16 @@
  *
  * usage: refprobe <out.json> [seed]
  *        refprobe --hashtable <out.json> [seed]
+ *        refprobe --hashtable-stress <out.tbl> <adds> [seed] [buckets]
+ *        refprobe --hashtable-ingest <out.tbl> <records> [seed] [buckets] [threads]
+ *
+ * oracle/Makefile links this source twice: _ref/refprobe with the reference's HashTable.o, _ref/refprobe_kng with
+ * kangaroo_amd/host/HashTable_kng.o in its place.  The two --hashtable* modes must then write the same bytes.
  */
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -27,6 +33,10 @@
 #include "Timer.h"
 
 static FILE *out;
+
+/* HashTable_kng.cpp keeps a bucket as two ascending runs between Adds and folds them for every reader the reference has
+ * (SaveTable, LoadTable); this probe reads E[h].items directly, so it asks for the fold when that object is linked in */
+extern "C" void kng_ht_normalize(HashTable *ht) __attribute__((weak));
 
 static std::string hex4(Int &a) {
   char buf[80];
@@ -324,6 +334,7 @@ static void emit_hashtable(const char *path, uint32_t seed) {
     if (st == ADD_COLLISION) fprintf(f, ",\"%s\",%u", hex4(ht->kDist).c_str(), ht->kType);
     fprintf(f, "]%s\n", i + 1 < xs.size() ? "," : "");
   }
+  if (kng_ht_normalize) kng_ht_normalize(ht);
   fprintf(f, "],\n\"count\":%" PRIu64 ",\n\"buckets\":[\n", ht->GetNbItem());
   bool first = true;
   for (uint32_t h = 0; h < HASH_SIZE; h++) {
@@ -341,6 +352,284 @@ static void emit_hashtable(const char *path, uint32_t seed) {
   fclose(f);
 }
 
+
+/* A long add sequence through `class HashTable` that whichever object is linked in must answer identically: deep buckets
+ * (`buckets` distinct bucket indices share `adds` points), equal high words of x, exact repeats, same x with another distance,
+ * all three Add overloads, a SaveTable / LoadTable round trip half way, and MergeH of two overlapping tables.  Everything
+ * observable goes to stdout (one line) and to the files <path>, <path>.merge. */
+static uint64_t fnv(uint64_t h, const void *p, size_t n) {
+  const unsigned char *c = (const unsigned char *)p;
+  for (size_t i = 0; i < n; i++) h = (h ^ c[i]) * 0x100000001B3ULL;
+  return h;
+}
+static uint64_t file_hash(const char *path, uint64_t *size) {
+  FILE *f = fopen(path, "rb");
+  if (!f) exit(1);
+  uint64_t h = 0xCBF29CE484222325ULL, n = 0;
+  unsigned char buf[65536];
+  size_t got;
+  while ((got = fread(buf, 1, sizeof buf, f)) > 0) {
+    h = fnv(h, buf, got);
+    n += got;
+  }
+  fclose(f);
+  *size = n;
+  return h;
+}
+static void hashtable_stress(const char *path, uint64_t adds, uint32_t seed, uint32_t buckets) {
+  rseed(seed);
+  Secp256K1 *secp = new Secp256K1();
+  secp->Init(); /* the group order behind ModNegK1order */
+  HashTable *ht = new HashTable();
+  HashTable *other = new HashTable();
+  std::vector<Int> xs, ds;
+  std::vector<uint32_t> types;
+  std::vector<uint64_t> hs(buckets);
+  for (uint32_t i = 0; i < buckets; i++) hs[i] = rndl() & HASH_MASK;
+  hs[0] = 0;
+  if (buckets > 1) hs[1] = HASH_MASK;
+  uint64_t sh = 0xCBF29CE484222325ULL, counts[3] = {0, 0, 0};
+  const size_t keep = 4096;
+  for (uint64_t i = 0; i < adds; i++) {
+    Int x, d;
+    x.Rand(256);
+    x.bits64[2] = (x.bits64[2] & ~(uint64_t)HASH_MASK) | hs[rndl() % buckets];
+    const int mode = (int)(rndl() % 32);
+    if (mode == 0 && !xs.empty()) x.bits64[1] = xs[rndl() % xs.size()].bits64[1]; /* key tie, other low word */
+    if (mode == 1) { /* clustered keys: interpolation has to fall back to the search */
+      x.bits64[1] &= 0xFFFF;
+    }
+    d.Rand(126);
+    if (rndl() % 3 == 0) d.ModNegK1order();
+    uint32_t type = (uint32_t)(rndl() & 1);
+    if (!xs.empty() && mode == 2) {
+      const size_t k = rndl() % xs.size();
+      x.Set(&xs[k]); d.Set(&ds[k]); type = types[k];
+    } else if (!xs.empty() && mode == 3) {
+      x.Set(&xs[rndl() % xs.size()]);
+    }
+    if (xs.size() < keep) {
+      xs.push_back(x); ds.push_back(d); types.push_back(type);
+    } else {
+      const size_t k = rndl() % keep;
+      xs[k] = x; ds[k] = d; types[k] = type;
+    }
+    int st;
+    const int how = (int)(i % 3);
+    if (how == 0) {
+      st = ht->Add(&x, &d, type);
+    } else {
+      uint64_t h;
+      int128_t X, D;
+      HashTable::Convert(&x, &d, type, &h, &X, &D);
+      if (how == 1) {
+        st = ht->Add(h, &X, &D);
+      } else {
+        ENTRY *e = (ENTRY *)malloc(sizeof(ENTRY));
+        e->x = X; e->d = D;
+        st = ht->Add(h, e);
+      }
+    }
+    counts[st]++;
+    sh = fnv(sh, &st, sizeof st);
+    if (st == ADD_COLLISION) {
+      sh = fnv(sh, ht->kDist.bits64, 32);
+      sh = fnv(sh, &ht->kType, sizeof(uint32_t));
+    }
+    if (i % 5 == 0) (void)other->Add(&x, &d, type ^ (uint32_t)(i % 7 == 0)); /* overlaps ht, sometimes with another type word */
+    if (i == adds / 2) { /* what -ws / -i do */
+      std::string tmp = std::string(path) + ".half";
+      FILE *f = fopen(tmp.c_str(), "wb");
+      ht->SaveTable(f, 0, HASH_SIZE, false);
+      fclose(f);
+      f = fopen(tmp.c_str(), "rb");
+      ht->LoadTable(f);
+      fclose(f);
+      remove(tmp.c_str());
+    }
+  }
+  FILE *f = fopen(path, "wb");
+  ht->SaveTable(f, 0, HASH_SIZE, false);
+  fclose(f);
+  std::string p2 = std::string(path) + ".other", pm = std::string(path) + ".merge";
+  f = fopen(p2.c_str(), "wb");
+  other->SaveTable(f, 0, HASH_SIZE, false);
+  fclose(f);
+  FILE *f1 = fopen(path, "rb"), *f2 = fopen(p2.c_str(), "rb"), *fm = fopen(pm.c_str(), "wb");
+  uint64_t mh = 0xCBF29CE484222325ULL, merged = 0, dups = 0, colls = 0;
+  for (uint32_t h = 0; h < HASH_SIZE; h++) {
+    uint32_t nb = 0, dup = 0, k1 = 0, k2 = 0;
+    Int d1, d2;
+    d1.SetInt32(0); d2.SetInt32(0);
+    const int st = HashTable::MergeH(h, f1, f2, fm, &nb, &dup, &d1, &k1, &d2, &k2);
+    merged += nb;
+    dups += dup;
+    if (st == ADD_COLLISION) {
+      colls++;
+      mh = fnv(mh, d1.bits64, 32); mh = fnv(mh, &k1, 4);
+      mh = fnv(mh, d2.bits64, 32); mh = fnv(mh, &k2, 4);
+    }
+  }
+  fclose(f1); fclose(f2); fclose(fm);
+  remove(p2.c_str());
+  /* the merged file loaded back: the table every later Add would search */
+  HashTable *back = new HashTable();
+  f = fopen(pm.c_str(), "rb");
+  back->LoadTable(f);
+  fclose(f);
+  uint64_t bh = 0xCBF29CE484222325ULL;
+  for (uint32_t h = 0; h < HASH_SIZE; h++)
+    for (uint32_t i = 0; i < back->E[h].nbItem; i++) bh = fnv(bh, back->E[h].items[i], 32);
+  uint64_t sz = 0, szm = 0;
+  const uint64_t th = file_hash(path, &sz), tmh = file_hash(pm.c_str(), &szm);
+  printf("adds %" PRIu64 " ok %" PRIu64 " dup %" PRIu64 " coll %" PRIu64 " statuses %016" PRIx64 " items %" PRIu64 " table %016" PRIx64
+         " bytes %" PRIu64 " merged %" PRIu64 " mdup %" PRIu64 " mcoll %" PRIu64 " mcollhash %016" PRIx64 " mergefile %016" PRIx64 " bytes %" PRIu64
+         " loaded %016" PRIx64 " %" PRIu64 "\n",
+         adds, counts[0], counts[1], counts[2], sh, ht->GetNbItem(), th, sz, merged, dups, colls, mh, tmh, szm, bh, back->GetNbItem());
+}
+
+/* The batch interface of HashTable_kng.cpp (kng_hashtable_ext.h) against the per-point path it stands in for.  Engine
+ * records {x[4], device distance, kidx} go (A) through what GPUEngine::Launch + Kangaroo::AddToTable do per point
+ * (GPUEngine.cu:668-674: wild distance - offset mod n; HashTable::Add(Int*, Int*, type)) and, when the replacement object is
+ * linked in, (B) through kng_ht_ingest in one thread, in the same order -- statuses, collision read-backs and SaveTable bytes
+ * must agree -- and (C) through kng_ht_ingest from `threads` threads at once: same set of x, nothing lost.  Path A alone runs
+ * with the reference's HashTable.o too, and prints the same line. */
+struct probe_rec { uint64_t x[4], d[2], kidx, reserved; };
+struct probe_event { uint32_t index, status; uint64_t stored_d[2]; };
+extern "C" int kng_ht_ingest(HashTable *ht, const probe_rec *recs, uint32_t n, const uint64_t wild_off[2], probe_event *ev, uint32_t ev_cap,
+                             uint32_t *n_ev) __attribute__((weak));
+#include <pthread.h>
+struct ingest_job { HashTable *ht; const probe_rec *recs; uint32_t n; const uint64_t *off; uint32_t events; };
+static void *ingest_thread(void *p) {
+  ingest_job *j = (ingest_job *)p;
+  const uint32_t chunk = 4096;
+  for (uint32_t at = 0; at < j->n; at += chunk) {
+    uint32_t ne = 0;
+    kng_ht_ingest(j->ht, j->recs + at, j->n - at < chunk ? j->n - at : chunk, j->off, NULL, 0, &ne);
+    j->events += ne;
+  }
+  return NULL;
+}
+static void hashtable_ingest(const char *path, uint32_t n, uint32_t seed, uint32_t buckets, int threads) {
+  rseed(seed);
+  Secp256K1 *secp = new Secp256K1();
+  secp->Init();
+  Int off;
+  off.SetInt32(0);
+  off.bits64[1] = 1ULL << 60; /* N/2 of a 125-bit range */
+  const uint64_t off2[2] = {off.bits64[0], off.bits64[1]};
+  std::vector<probe_rec> recs(n);
+  std::vector<uint64_t> hs(buckets);
+  for (uint32_t i = 0; i < buckets; i++) hs[i] = rndl() & HASH_MASK;
+  for (uint32_t i = 0; i < n; i++) {
+    probe_rec &r = recs[i];
+    Int x, d;
+    x.Rand(256);
+    d.Rand(126);
+    const int mode = (int)(rndl() % 24);
+    if (mode == 0) { d.SetInt32(0); d.bits64[1] = 1ULL << 60; }              /* device distance == offset: true distance 0 */
+    if (mode == 1) { d.SetInt32(0); d.bits64[0] = rndl(); }                    /* far below the offset: negative */
+    memcpy(r.x, x.bits64, 32);
+    r.x[2] = (r.x[2] & ~(uint64_t)HASH_MASK) | hs[rndl() % buckets];
+    r.d[0] = d.bits64[0];
+    r.d[1] = d.bits64[1];
+    r.kidx = rndl();
+    r.reserved = 0;
+    if (i && mode == 2) r = recs[rndl() % i];                                   /* the same point again */
+    if (i && mode == 3) { memcpy(r.x, recs[rndl() % i].x, 32); }                /* same x, other distance */
+    if (i && mode == 4) r.x[1] = recs[rndl() % i].x[1];                         /* key tie */
+  }
+  /* (A) */
+  HashTable *a = new HashTable();
+  uint64_t sh = 0xCBF29CE484222325ULL, counts[3] = {0, 0, 0};
+  std::vector<probe_event> want;
+  for (uint32_t i = 0; i < n; i++) {
+    Int x, d;
+    x.SetInt32(0); d.SetInt32(0);
+    memcpy(x.bits64, recs[i].x, 32);
+    d.bits64[0] = recs[i].d[0];
+    d.bits64[1] = recs[i].d[1];
+    const uint32_t type = (uint32_t)(recs[i].kidx % 2);
+    if (type == 1) d.ModSubK1order(&off);
+    const int st = a->Add(&x, &d, type);
+    counts[st]++;
+    sh = fnv(sh, &st, sizeof st);
+    if (st == ADD_COLLISION) {
+      sh = fnv(sh, a->kDist.bits64, 32);
+      sh = fnv(sh, &a->kType, sizeof(uint32_t));
+    }
+    if (st != ADD_OK) {
+      probe_event e = {i, (uint32_t)st, {0, 0}};
+      if (st == ADD_COLLISION) { /* re-encode what Add decoded, to compare with the raw word path B returns */
+        Int kd(&a->kDist);
+        uint64_t flags = (uint64_t)a->kType << 62;
+        if (kd.bits64[3] > 0x7FFFFFFFFFFFFFFFULL) { kd.ModNegK1order(); flags |= 1ULL << 63; }
+        e.stored_d[0] = kd.bits64[0];
+        e.stored_d[1] = (kd.bits64[1] & 0x3FFFFFFFFFFFFFFFULL) | flags;
+      }
+      want.push_back(e);
+    }
+  }
+  FILE *f = fopen(path, "wb");
+  a->SaveTable(f, 0, HASH_SIZE, false);
+  fclose(f);
+  uint64_t sz = 0;
+  const uint64_t th = file_hash(path, &sz);
+  printf("records %u ok %" PRIu64 " dup %" PRIu64 " coll %" PRIu64 " statuses %016" PRIx64 " table %016" PRIx64 " bytes %" PRIu64 "\n", n, counts[0],
+         counts[1], counts[2], sh, th, sz);
+  if (!kng_ht_ingest) return;
+  /* (B) */
+  HashTable *b = new HashTable();
+  std::vector<probe_event> got;
+  const uint32_t chunk = 3000;
+  std::vector<probe_event> ev(chunk);
+  for (uint32_t at = 0; at < n; at += chunk) {
+    const uint32_t m = n - at < chunk ? n - at : chunk;
+    uint32_t ne = 0;
+    kng_ht_ingest(b, recs.data() + at, m, off2, ev.data(), chunk, &ne);
+    for (uint32_t k = 0; k < ne; k++) {
+      ev[k].index += at;
+      got.push_back(ev[k]);
+    }
+  }
+  bool same = got.size() == want.size();
+  for (size_t k = 0; same && k < got.size(); k++)
+    same = got[k].index == want[k].index && got[k].status == want[k].status && got[k].stored_d[0] == want[k].stored_d[0] &&
+           got[k].stored_d[1] == want[k].stored_d[1];
+  std::string pb = std::string(path) + ".ingest";
+  f = fopen(pb.c_str(), "wb");
+  b->SaveTable(f, 0, HASH_SIZE, false);
+  fclose(f);
+  uint64_t szb = 0;
+  const uint64_t thb = file_hash(pb.c_str(), &szb);
+  printf("ingest: events %zu/%zu %s, table %s\n", got.size(), want.size(), same ? "identical" : "DIFFERENT",
+         thb == th && szb == sz ? "identical" : "DIFFERENT");
+  /* (C) */
+  HashTable *c = new HashTable();
+  std::vector<ingest_job> jobs(threads);
+  std::vector<pthread_t> tid(threads);
+  for (int t = 0; t < threads; t++) {
+    const uint32_t lo = (uint32_t)((uint64_t)n * t / threads), hi = (uint32_t)((uint64_t)n * (t + 1) / threads);
+    jobs[t] = {c, recs.data() + lo, hi - lo, off2, 0};
+    pthread_create(&tid[t], NULL, ingest_thread, &jobs[t]);
+  }
+  uint64_t events = 0;
+  for (int t = 0; t < threads; t++) {
+    pthread_join(tid[t], NULL);
+    events += jobs[t].events;
+  }
+  kng_ht_normalize(c);
+  bool xs_same = c->GetNbItem() == a->GetNbItem();
+  kng_ht_normalize(a);
+  for (uint32_t h = 0; xs_same && h < HASH_SIZE; h++) {
+    xs_same = c->E[h].nbItem == a->E[h].nbItem;
+    for (uint32_t i = 0; xs_same && i < c->E[h].nbItem; i++)
+      xs_same = c->E[h].items[i]->x.i64[0] == a->E[h].items[i]->x.i64[0] && c->E[h].items[i]->x.i64[1] == a->E[h].items[i]->x.i64[1];
+  }
+  printf("ingest x%d threads: %" PRIu64 " entries + %" PRIu64 " events = %" PRIu64 " of %u, x set %s\n", threads, c->GetNbItem(), events,
+         c->GetNbItem() + events, n, xs_same && c->GetNbItem() + events == n ? "identical" : "DIFFERENT");
+}
+
 int main(int argc, char **argv) {
   if (argc < 2) {
     fprintf(stderr, "usage: %s <out.json> [seed]\n", argv[0]);
@@ -349,6 +638,18 @@ int main(int argc, char **argv) {
   if (argc >= 3 && std::string(argv[1]) == "--hashtable") {
     Timer::Init();
     emit_hashtable(argv[2], argc > 3 ? (uint32_t)strtoul(argv[3], NULL, 0) : 0x7AB1E001u);
+    return 0;
+  }
+  if (argc >= 4 && std::string(argv[1]) == "--hashtable-stress") {
+    Timer::Init();
+    hashtable_stress(argv[2], strtoull(argv[3], NULL, 0), argc > 4 ? (uint32_t)strtoul(argv[4], NULL, 0) : 0x57E55001u,
+                     argc > 5 ? (uint32_t)strtoul(argv[5], NULL, 0) : 48);
+    return 0;
+  }
+  if (argc >= 4 && std::string(argv[1]) == "--hashtable-ingest") {
+    Timer::Init();
+    hashtable_ingest(argv[2], (uint32_t)strtoul(argv[3], NULL, 0), argc > 4 ? (uint32_t)strtoul(argv[4], NULL, 0) : 0x1465E501u,
+                     argc > 5 ? (uint32_t)strtoul(argv[5], NULL, 0) : 4096, argc > 6 ? atoi(argv[6]) : 4);
     return 0;
   }
   uint32_t seed = argc > 2 ? (uint32_t)strtoul(argv[2], NULL, 0) : 0x5EED1234u;

@@ -30,12 +30,13 @@ def _decompress(pub_hex):
     return x, y
 
 
-def test_reference_program_solves_25_keys_one_engine_per_key(kng):
+@pytest.mark.parametrize("program", ["kangaroo_hip", "kangaroo_mi355x"])
+def test_reference_program_solves_25_keys_one_engine_per_key(kng, program):
     """`kangaroo_hip -t 0 -gpu -g 32,128 in40_25keys.txt`: the unmodified program creates, uses and deletes one GPUEngine
     per key.  Every printed private key must lie in the range and reproduce its public key; 25 keys, 25 answers."""
     import kangaroo_amd.hostlib as hl
 
-    exe = ref_binary("kangaroo_hip")
+    exe = ref_binary(program)
     cfg = os.path.join(ROOT, "tests", "golden", "in40_25keys.txt")
     lines = [l.strip() for l in open(cfg) if l.strip()]
     start, end, pubs = int(lines[0], 16), int(lines[1], 16), lines[2:]

@@ -485,13 +485,14 @@ def test_allocation_failure_is_reported_not_fatal(kng):
         assert eng.nbKangaroo == 512
 
 
-def test_reference_gpu_check_harness_on_our_engine():
+@pytest.mark.parametrize("program", ["kangaroo_hip", "kangaroo_mi355x"])
+def test_reference_gpu_check_harness_on_our_engine(program):
     """The reference's own CPU/GPU parity harness, `kangaroo -gpu -check` (Check.cpp:467-621), unmodified, on our
     engine: SetKangaroos, single SetKangaroo, Launch x2, GetKangaroos against SECPK1 AddDirect, every DP found.
     -g 8,128 keeps the herd below Check's hard-coded maxFound (65536 DPs at dp=8, Check.cpp:418,492)."""
     import subprocess
 
-    exe = ref_binary("kangaroo_hip")
+    exe = ref_binary(program)
     out = subprocess.run([exe, "-gpu", "-g", "8,128", "-check"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "CPU/GPU ok" in out.stdout, out.stdout[-2500:] + out.stderr[-500:]
     assert "DP found" in out.stdout and "warning" not in out.stdout.lower()
@@ -553,26 +554,28 @@ def test_solve_in_txt_with_python_host(kng):
     assert launch < 200
 
 
-def test_reference_program_solves_in_txt_on_our_engine(tmp_path):
+@pytest.mark.parametrize("program", ["kangaroo_hip", "kangaroo_mi355x"])
+def test_reference_program_solves_in_txt_on_our_engine(tmp_path, program):
     """The unmodified reference program (oracle/_ref/kangaroo_hip = reference host code + our
     GPUEngine) solving its own shipped known-answer input on the MI355X."""
     import subprocess
 
-    exe = ref_binary("kangaroo_hip")
+    exe = ref_binary(program)
     cfg = tmp_path / "in.txt"
     cfg.write_text("0\n%X\n%s\n" % (IN_TXT_RANGE_END, IN_TXT_PUBKEY))
     out = subprocess.run([exe, "-t", "0", "-gpu", "-g", "16,128", str(cfg)], capture_output=True, text=True, timeout=300)
     assert "Priv: 0x%X" % IN_TXT_ANSWER in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
 
 
-def test_reference_program_drives_two_engines_concurrently(tmp_path):
+@pytest.mark.parametrize("program", ["kangaroo_hip", "kangaroo_mi355x"])
+def test_reference_program_drives_two_engines_concurrently(tmp_path, program):
     """The reference's own thread-per-engine path over the boundary (Kangaroo.cpp:1041-1047: one _SolveKeyGPU pthread per
     -gpuId entry): `-gpuId 0,0` makes the unmodified program create TWO GPUEngine instances and drive them from two
     host threads at once, feeding one HashTable.  SURVEY 8(b): distinct instances from distinct threads must work
     (every entry point selects its own device, nothing is global)."""
     import subprocess
 
-    exe = ref_binary("kangaroo_hip")
+    exe = ref_binary(program)
     cfg = tmp_path / "in.txt"
     cfg.write_text("0\n%X\n%s\n" % (IN_TXT_RANGE_END, IN_TXT_PUBKEY))
     out = subprocess.run([exe, "-t", "0", "-gpu", "-gpuId", "0,0", "-g", "32,128,32,128", str(cfg)], capture_output=True, text=True, timeout=300)
@@ -580,12 +583,13 @@ def test_reference_program_drives_two_engines_concurrently(tmp_path):
     assert "Priv: 0x%X" % IN_TXT_ANSWER in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
 
 
-def test_reference_program_solves_64bit_range_on_our_engine(tmp_path):
+@pytest.mark.parametrize("program", ["kangaroo_hip", "kangaroo_mi355x"])
+def test_reference_program_solves_64bit_range_on_our_engine(tmp_path, program):
     """BASELINE.json configs[1]: the reference's shipped 64-bit known-answer input (VC_CUDA8/in64.txt,
     answer README.md:194-195) solved by the unmodified reference program on our engine."""
     import subprocess
 
-    exe = ref_binary("kangaroo_hip")
+    exe = ref_binary(program)
     cfg = tmp_path / "in64.txt"
     cfg.write_text("5B3F38AF935A3640D158E871CE6E9666DB862636383386EE0000000000000000\n"
                    "5B3F38AF935A3640D158E871CE6E9666DB862636383386EEFFFFFFFFFFFFFFFF\n"
@@ -622,7 +626,8 @@ def _run_until_saves(cmd, n_saves, max_seconds):
     return buf.decode(errors="replace")
 
 
-def test_reference_workfile_roundtrip_125bit_on_our_engine(tmp_path, orc):
+@pytest.mark.parametrize("program", ["kangaroo_hip", "kangaroo_mi355x"])
+def test_reference_workfile_roundtrip_125bit_on_our_engine(tmp_path, orc, program):
     """BASELINE.json configs[4] on one GPU: 125-bit (maximum) range, `-ws -w f -wi 3` save through
     GetKangaroos, `-winfo` / `-wcheck` of the file, `-i f` restore through SetKangaroos -- all by the
     unmodified reference program (Backup.cpp, Check.cpp) on our engine -- plus an independent check of
@@ -630,7 +635,7 @@ def test_reference_workfile_roundtrip_125bit_on_our_engine(tmp_path, orc):
     import re
     import subprocess
 
-    exe = ref_binary("kangaroo_hip")
+    exe = ref_binary(program)
     cfg = tmp_path / "in125.txt"
     cfg.write_text("0\n1FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF\n%s\n" % IN_TXT_PUBKEY)
     f1, f2 = str(tmp_path / "a.work"), str(tmp_path / "b.work")

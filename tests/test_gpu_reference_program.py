@@ -1,0 +1,136 @@
+"""The reference PROGRAM at the rate of the kernel (SURVEY 8 f1 / f4 brought to the CLI).
+
+oracle/_ref/kangaroo_hip    = the reference's host code, unmodified, + our `class GPUEngine` (the drop-in boundary);
+oracle/_ref/kangaroo_mi355x = the same objects with HashTable.o and the Kangaroo::SolveKeyGPU symbol replaced at LINK time by
+                              kangaroo_amd/host/HashTable_kng.cpp and SolveKeyGPU_kng.cpp (no reference source edited).
+Both are built by oracle/Makefile where /root/reference exists and travel to the GPU box with the tree."""
+import os
+import re
+import shutil
+import signal
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+from helpers import ref_binary
+
+pytestmark = pytest.mark.gpu
+
+# BASELINE configs[2]: 80-bit range.  The public key is NOT in the range (it is the key of in64.txt): the search cannot end,
+# the herd and the table behave as in any unsolved run.
+IN80 = ("B60E83280258A40F9CDF1649744D730D6E939DE92A2B00000000000000000000\n"
+        "B60E83280258A40F9CDF1649744D730D6E939DE92A2BFFFFFFFFFFFFFFFFFFFF\n"
+        "03BB113592002132E6EF387C3AEBC04667670D4CD40B2103C7D0EE4969E9FF56E4\n")
+STATUS = re.compile(r"\[([0-9.]+) MK/s\]\[GPU [0-9.]+ MK/s\]\[Count 2\^([0-9.]+)\]\[Dead (\d+)\]\[(\d+):(\d+)(?::(\d+))? .*?\]\[([0-9.]+)/([0-9.]+)(MB|GB)\]")
+
+
+def _run(cmd, seconds, env=None, until=None):
+    """Run the program unbuffered for `seconds` after its walk has started (or until `until` appears), stop it, return output."""
+    e = dict(os.environ)
+    e.update(env or {})
+    if shutil.which("stdbuf"):
+        cmd = ["stdbuf", "-o0", "-e0"] + cmd
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=e, start_new_session=True)
+    os.set_blocking(proc.stdout.fileno(), False)
+    buf, started, t0 = b"", None, time.time()
+    while time.time() - t0 < seconds + 240 and proc.poll() is None:
+        time.sleep(0.25)
+        try:
+            chunk = proc.stdout.read()
+        except BlockingIOError:
+            chunk = None
+        if chunk:
+            buf += chunk
+        if started is None and b"kangaroos [" in buf:
+            started = time.time()
+        if until and until.encode() in buf:
+            break
+        if started is not None and time.time() - started > seconds:
+            break
+    if proc.poll() is None:
+        os.killpg(proc.pid, signal.SIGKILL)
+    proc.wait()
+    try:
+        rest = proc.stdout.read()
+        if rest:
+            buf += rest
+    except Exception:
+        pass
+    return buf.decode(errors="replace").replace("\r", "\n")
+
+
+def _status_lines(text):
+    out = []
+    for m in STATUS.finditer(text):
+        a, b, c = int(m.group(4)), int(m.group(5)), m.group(6)
+        secs = a * 3600 + b * 60 + int(c) if c is not None else a * 60 + b
+        used = float(m.group(7)) * (1024.0 if m.group(9) == "GB" else 1.0)
+        out.append({"mks": float(m.group(1)), "count": 2.0 ** float(m.group(2)), "t": secs, "used_mb": used})
+    return out
+
+
+def _kernel_rate_gks(kng):
+    """jumps per second of the walk kernel alone at the reference program's default grid (HIP events, 12 launches)."""
+    import kangaroo_amd.hostlib as hl
+
+    gx, gy = kng.default_grid(0)
+    jd, jx, jy, _ = hl.jump_table(80)
+    with kng.GPUEngine(gx, gy, 0, 1 << 17) as eng:
+        eng.SetParams(hl.dp_mask(14), jd, jx, jy)
+        eng.CreateHerdOnDevice(80, seed=5)
+        ms = []
+        for _ in range(15):
+            eng.callKernel()
+            eng.wait()
+            eng.drain(raw=True)
+            ms.append(eng.last_kernel_ms())
+        return eng.nbKangaroo * 64 / (np.median(ms[3:]) * 1e-3) / 1e9
+
+
+def test_reference_program_runs_at_the_kernel_rate_at_its_own_dp(kng, tmp_path):
+    """`kangaroo_mi355x -t 0 -gpu in80.txt`: default grid (2^23 kangaroos), the DP size the program suggests itself (14), no
+    other option.  The unmodified program on the same engine does 19 GK/s in its first minute and 12 GK/s over three (its
+    HashTable and its lock-step loop, profiles/r03_*); with the two link-time replacements the GPU thread never waits for the
+    host: >= 0.95 of the kernel-only rate, measured over ~50 s here (and over three minutes in profiles/r05_*).  The exact
+    figure is the program's own launch count over its own clock (KNG_STATS line); the status line's Count column, which has a
+    resolution of 0.7 % in count and 1 s in time, must agree within 6 %."""
+    exe = ref_binary("kangaroo_mi355x")
+    kernel = _kernel_rate_gks(kng)
+    cfg = tmp_path / "in80.txt"
+    cfg.write_text(IN80)
+    text = _run([exe, "-t", "0", "-gpu", "-m", "0.42", str(cfg)], 150, env={"KNG_STATS": "1"}, until="SolveKeyGPU_kng GPU#0")
+    assert "Suggested DP: 14" in text and "items lost" not in text, text[-1500:]
+    m = re.search(r"SolveKeyGPU_kng GPU#0: (\d+) launches in ([0-9.]+) s = ([0-9.]+) MK/s; points (\d+) \(lost (\d+)\), events (\d+); "
+                  r"GPU thread waited ([0-9.]+) s for kernels, ([0-9.]+) s for queue room", text)
+    assert m, text[-2500:]
+    launches, wall, mks, points, lost = int(m.group(1)), float(m.group(2)), float(m.group(3)), int(m.group(4)), int(m.group(5))
+    assert launches > 1500 and lost == 0
+    assert abs(points / launches - 32768) < 600                      # 2^29 jumps / 2^14 per launch, every one delivered
+    assert mks / 1e3 >= 0.95 * kernel, (mks, kernel, text[-600:])
+    st = [s for s in _status_lines(text) if s["t"] >= 8]
+    assert len(st) >= 10
+    by_count = (st[-1]["count"] - st[0]["count"]) / (st[-1]["t"] - st[0]["t"]) / 1e9
+    assert abs(by_count / (mks / 1e3) - 1) < 0.06, (by_count, mks)
+    # the table really holds them: 32 bytes per point in the "used" figure of the status line
+    assert abs(st[-1]["used_mb"] * 1048576 / 32 / (st[-1]["count"] / 2 ** 14) - 1) < 0.05
+
+
+@pytest.mark.parametrize("program", ["kangaroo_hip", "kangaroo_mi355x"])
+def test_maxfound_of_the_program_is_a_floor_not_a_ceiling(tmp_path, program):
+    """`-g 512,128 -d 11` (the DP size the program suggests for eight MI355X): a launch yields 262 144 points, twice the
+    `maxFound = 65536*2` the program hard-codes (Kangaroo.cpp:523).  The shim sizes the engine from herd and mask in SetParams:
+    nothing is lost, no warning, and the table grows by one point per 2^11 jumps."""
+    exe = ref_binary(program)
+    cfg = tmp_path / "in80.txt"
+    cfg.write_text(IN80)
+    text = _run([exe, "-t", "0", "-gpu", "-g", "512,128", "-d", "11", str(cfg)], 14, env={"KNG_STATS": "1"})
+    assert "DP size: 11" in text and "items lost" not in text and "Warning" not in text, text[-1500:]
+    st = _status_lines(text)
+    assert len(st) >= 3, text[-1500:]
+    last = st[-1]
+    stored = last["used_mb"] * 1048576 / 32 - 2 ** 18 * 8 / 32   # "used" = 8 bytes per bucket + 32 per point (HashTable.cpp:328)
+    # the status thread reads counters and table at slightly different moments, and points of the last launches are still on
+    # their way: a band, but one that a table missing half of every launch (131 072 of 262 144) cannot reach
+    assert 0.80 < stored / (last["count"] / 2 ** 11) < 1.05, (stored, last)

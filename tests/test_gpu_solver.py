@@ -142,9 +142,11 @@ def test_save_restore_continue_and_reference_reads_it(sv, orc, tmp_path, start, 
     t2.close()
 
 
-def test_reference_program_resumes_from_our_workfile(sv, tmp_path):
-    """`kangaroo -i ours.work` (reference host code on our engine): loads our table and herd and finishes the solve."""
-    ref_binary("kangaroo_hip")
+@pytest.mark.parametrize("program", ["kangaroo_hip", "kangaroo_mi355x"])
+def test_reference_program_resumes_from_our_workfile(sv, tmp_path, program):
+    """`kangaroo -i ours.work` (reference host code on our engine; kangaroo_mi355x = the same with HashTable and SolveKeyGPU
+    replaced at link time): loads our table and herd and finishes the solve."""
+    exe = ref_binary(program)
     start, end, pub, answer = IN64
     grid = (64, 128)
     s = sv.Solver(start, end, _decompress(pub), grid=grid, seed=21, max_launches=3)
@@ -156,7 +158,7 @@ def test_reference_program_resumes_from_our_workfile(sv, tmp_path):
     s.close()
     if rc == 1:
         pytest.skip("solved before the save (lucky herd)")
-    out = subprocess.run([REF_HIP, "-t", "0", "-gpu", "-g", "%d,%d" % grid, "-i", path], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([exe, "-t", "0", "-gpu", "-g", "%d,%d" % grid, "-i", path], capture_output=True, text=True, timeout=600)
     assert "Priv: 0x%X" % answer in out.stdout, out.stdout[-2500:] + out.stderr[-500:]
     assert "Fetch kangaroos" in out.stdout or "LoadWork" in out.stdout
 

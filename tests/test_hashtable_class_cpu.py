@@ -1,0 +1,71 @@
+"""`class HashTable` of the reference re-implemented for link-time replacement (kangaroo_amd/host/HashTable_kng.cpp, SURVEY 8 f4,
+VERDICT r4 item 1).  oracle/Makefile links the probe oracle/refprobe.cpp twice: `refprobe` with the reference's HashTable.o,
+`refprobe_kng` with HashTable_kng.o (compiled against the reference's own HashTable.h) in its place.  Whatever the class lets a
+caller observe -- Add statuses, kDist / kType after a collision, bucket contents, maxItem words, SaveTable / LoadTable / MergeH
+bytes -- must be the same from both.  The binaries are built where /root/reference exists and travel with the tree."""
+import filecmp
+import json
+import os
+import subprocess
+
+import pytest
+
+from helpers import ref_binary
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(exe, *args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=600, env=e)
+    assert out.returncode == 0, out.stdout[-800:] + out.stderr[-800:]
+    return [ln for ln in out.stdout.splitlines() if ln and not ln.startswith(("Jump Avg", "DP size", "Range width"))]
+
+
+def test_golden_add_sequence_through_the_replacement_class(tmp_path):
+    """The committed golden sequence (tests/golden/ref_hashtable.json, written by the REFERENCE's HashTable::Add: 900 adds
+    with repeats, collisions, negative distances, crowded buckets) replayed through HashTable_kng.o by the same probe."""
+    exe = ref_binary("refprobe_kng")
+    out = tmp_path / "ht.json"
+    _run(exe, "--hashtable", out)
+    with open(out) as f, open(os.path.join(ROOT, "tests", "golden", "ref_hashtable.json")) as g:
+        got, want = json.load(f), json.load(g)
+    assert got["adds"] == want["adds"]          # statuses and collision read-backs
+    assert got["count"] == want["count"]
+    assert got["buckets"] == want["buckets"]    # nbItem, maxItem, entries in order, for every bucket touched
+
+
+@pytest.mark.parametrize("adds,seed,buckets,tail", [
+    (120000, 1, 48, None),      # ~2500 entries per bucket: every size class, many folds
+    (120000, 7, 3, None),       # 40 000 per bucket
+    (60000, 9, 4096, None),     # small buckets only
+    (80000, 5, 3, 0),           # KNG_HT_TAIL=0: folded after every insertion (the reference's invariant at all times)
+    (80000, 5, 3, 1),
+    (80000, 5, 3, 4096),
+])
+def test_stress_sequence_equals_the_reference_class(tmp_path, adds, seed, buckets, tail):
+    """A long sequence through all three Add overloads, a SaveTable / LoadTable round trip half way, MergeH of two overlapping
+    tables and LoadTable of the merge: one stdout line (status hash, kDist / kType hash, counts) and two files, both programs."""
+    ref, kng = ref_binary("refprobe"), ref_binary("refprobe_kng")
+    a, b = tmp_path / "ref.tbl", tmp_path / "kng.tbl"
+    la = _run(ref, "--hashtable-stress", a, adds, seed, buckets)
+    lb = _run(kng, "--hashtable-stress", b, adds, seed, buckets, env=None if tail is None else {"KNG_HT_TAIL": str(tail)})
+    assert la == lb and len(la) == 1 and " coll " in la[0]
+    assert filecmp.cmp(a, b, shallow=False)
+    assert filecmp.cmp(str(a) + ".merge", str(b) + ".merge", shallow=False)
+
+
+@pytest.mark.parametrize("n,seed,buckets,threads", [(150000, 1, 4096, 4), (150000, 2, 7, 8), (100000, 3, 1, 3)])
+def test_batch_ingest_equals_the_per_point_path(tmp_path, n, seed, buckets, threads):
+    """kng_ht_ingest (what SolveKeyGPU_kng.cpp feeds the table with) against GPUEngine::Launch's conversion + HashTable::Add per
+    point: same statuses, same stored distance for every collision, same SaveTable bytes -- with the reference's object doing
+    the per-point path in one program and ours in the other -- and, from several threads at once, the same set of x with every
+    point either stored or reported."""
+    ref, kng = ref_binary("refprobe"), ref_binary("refprobe_kng")
+    a, b = tmp_path / "ref.tbl", tmp_path / "kng.tbl"
+    la = _run(ref, "--hashtable-ingest", a, n, seed, buckets, threads)
+    lb = _run(kng, "--hashtable-ingest", b, n, seed, buckets, threads)
+    assert la[0] == lb[0] and filecmp.cmp(a, b, shallow=False)
+    assert "identical, table identical" in lb[1], lb
+    assert lb[2].endswith("x set identical") and f"of {n}" in lb[2], lb
