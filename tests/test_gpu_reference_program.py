@@ -23,7 +23,17 @@ pytestmark = pytest.mark.gpu
 IN80 = ("B60E83280258A40F9CDF1649744D730D6E939DE92A2B00000000000000000000\n"
         "B60E83280258A40F9CDF1649744D730D6E939DE92A2BFFFFFFFFFFFFFFFFFFFF\n"
         "03BB113592002132E6EF387C3AEBC04667670D4CD40B2103C7D0EE4969E9FF56E4\n")
-STATUS = re.compile(r"\[([0-9.]+) MK/s\]\[GPU [0-9.]+ MK/s\]\[Count 2\^([0-9.]+)\]\[Dead (\d+)\]\[(\d+):(\d+)(?::(\d+))? .*?\]\[([0-9.]+)/([0-9.]+)(MB|GB)\]")
+# elapsed time as Kangaroo::GetTimeStr prints it (Thread.cpp:124-162): "42s", "01:10", "01:02:03"
+STATUS = re.compile(r"\[([0-9.]+) MK/s\]\[GPU [0-9.]+ MK/s\]\[Count 2\^([0-9.]+)\]\[Dead (\d+)\]\[([0-9:]+s?) \(Avg [^)]*\)\]\[([0-9.]+)/([0-9.]+)(MB|GB)\]")
+
+
+def _seconds(t):
+    if t.endswith("s"):
+        return int(t[:-1])
+    v = 0
+    for part in t.split(":"):
+        v = v * 60 + int(part)
+    return v
 
 
 def _run(cmd, seconds, env=None, until=None):
@@ -64,10 +74,8 @@ def _run(cmd, seconds, env=None, until=None):
 def _status_lines(text):
     out = []
     for m in STATUS.finditer(text):
-        a, b, c = int(m.group(4)), int(m.group(5)), m.group(6)
-        secs = a * 3600 + b * 60 + int(c) if c is not None else a * 60 + b
-        used = float(m.group(7)) * (1024.0 if m.group(9) == "GB" else 1.0)
-        out.append({"mks": float(m.group(1)), "count": 2.0 ** float(m.group(2)), "t": secs, "used_mb": used})
+        used = float(m.group(5)) * (1024.0 if m.group(7) == "GB" else 1.0)
+        out.append({"mks": float(m.group(1)), "count": 2.0 ** float(m.group(2)), "t": _seconds(m.group(4)), "used_mb": used})
     return out
 
 

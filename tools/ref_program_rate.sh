@@ -14,15 +14,22 @@ printf "B60E83280258A40F9CDF1649744D730D6E939DE92A2B00000000000000000000\nB60E83
 for prog in kangaroo_mi355x kangaroo_hip; do
   f=$OUT/ref_program_rate_${prog}.txt
   # -m: stop by itself after SECS seconds at 25 GK/s (so that the KNG_STATS line is printed); timeout is the backstop
-  M=$(python3 -c "print('%.3f' % ($SECS*25.0e9/2**41.58))")
+  M=$(python3 -c "print('%.3f' % ($SECS*25.6e9/2**${EXPECTED_LOG2:-41.11}))")   # "Expected operations: 2^41.11" at DP 14; set EXPECTED_LOG2 for other -d
   KNG_STATS=1 timeout $((SECS+60)) stdbuf -o0 -e0 $ROOT/oracle/_ref/$prog -t 0 -gpu -m $M "$@" in80.txt 2>&1 | tr "\r" "\n" > $f
   echo "== $prog $@"
   grep -v "^\[" $f | grep -v "^$" | head -24
   python3 - $f <<'PY'
 import re, sys
 st = []
-for m in re.finditer(r"\[([0-9.]+) MK/s\]\[GPU [0-9.]+ MK/s\]\[Count 2\^([0-9.]+)\]\[Dead (\d+)\]\[(\d+):(\d+) .*?\]\[([0-9.]+/[0-9.]+[MG]B)\]", open(sys.argv[1]).read()):
-    st.append((int(m.group(4)) * 60 + int(m.group(5)), 2.0 ** float(m.group(2)), m.group(6)))
+def secs(t):  # Kangaroo::GetTimeStr: "42s", "01:10", "01:02:03"
+    if t.endswith("s"):
+        return int(t[:-1])
+    v = 0
+    for part in t.split(":"):
+        v = v * 60 + int(part)
+    return v
+for m in re.finditer(r"\[([0-9.]+) MK/s\]\[GPU [0-9.]+ MK/s\]\[Count 2\^([0-9.]+)\]\[Dead (\d+)\]\[([0-9:]+s?) \(Avg [^)]*\)\]\[([0-9.]+/[0-9.]+[MG]B)\]", open(sys.argv[1]).read()):
+    st.append((secs(m.group(4)), 2.0 ** float(m.group(2)), m.group(5)))
 if len(st) > 4:
     for lo, hi in ((10, 60), (60, 120), (120, 1e9), (10, 1e9)):
         w = [s for s in st if lo <= s[0] <= hi]
