@@ -180,7 +180,14 @@ def _power_bound(power_summary, bytes_per_jump, rate_mks):
     out = {"formula": "(P_cap - P_static) / E_dyn_per_jump", "p_static_w": P_STATIC_W, "e_dyn_nj_per_jump": round(e_dyn, 2),
            "e_valu_nj_per_jump": round(E_VALU_NJ_PER_WAVE_JUMP / 64.0, 2), "e_mem_nj_per_jump": round(bytes_per_jump * E_MEM_NJ_PER_BYTE, 2),
            "bytes_per_jump": bytes_per_jump, "p_cap_w": cap,
-           "inputs": "profiles/r01_instr_energy.txt, profiles/r02_memory_energy.txt, static instruction count of tools/gen_walk_asm.py"}
+           # where each constant comes from -- none is measured in this run, each was probed once on ONE box of the pool
+           "inputs": {"p_static_w": "342 W: round 1, tools/instr_power.sh on one MI355X of the pool (profiles/r01_instr_energy.txt, s_nop on every SIMD)",
+                      "valu_nj_per_wave_instr": "MAD 1.38 / VOP3+carry 0.75 / move 0.36 nJ: same round-1 probe, same box",
+                      "mem_nj_per_byte": "0.100 nJ/B: round 2, tools/mem_power_probe.hip on another box (profiles/r02_memory_energy.txt: copy 102, read 93, write 115 pJ/B)",
+                      "instr_per_jump": "410 MAD + 475 slow + 140 fast VALU: static count of the loop tools/gen_walk_asm.py prints (this tree)",
+                      "bytes_per_jump": "roofline.traffic / jumps when a recorded figure applies, else the design figure 208",
+                      "p_cap_w": "rocm_smi power cap of the device of THIS run", "measured_power_w": "energy counter / samples of THIS run",
+                      "caveat": "boxes of the pool differ by a few per cent in leakage and clocks; the bound is a model, good to ~5 %"}}
     if cap:
         out["value_mks"] = round((cap - P_STATIC_W) / (e_dyn * 1e-9) / 1e6, 0)
     # the energy accumulator over the window where the device has one (exact average), else the median of the samples
@@ -243,7 +250,10 @@ def _recorded_traffic(n, group, kernel):
     changed = sorted(k for k in now if then.get(k) != now[k])
     if changed:
         return None, f"stale: {', '.join(changed)} changed since the PMC pass ({tj.get('source')})"
-    return tj.get("hbm_bytes_per_launch"), tj.get("source")
+    # say what it is: a figure RECORDED by an earlier PMC pass of the builder (rocprofv3 cannot wrap the driver's bench run),
+    # tied to this run only through the byte-identity of the kernel sources -- not bytes counted during this run
+    return tj.get("hbm_bytes_per_launch"), (f"RECORDED, not measured in this run: {tj.get('source')}; quoted because kernel, herd, group match and all "
+                                            f"{len(now)} kernel source files have the git blob ids of that pass (profiles/traffic.json)")
 
 
 def _timed_engine(k, hl, dev, gx, gy, range_power, key_xy, dp, steps, warmup, seed, **opts):
@@ -349,57 +359,67 @@ def bench_multi(args, ranks, n_gpus):
         ranks.abort()
         raise SystemExit(1)
     if ranks.rank == 0:
-        power = sampler.stop().summary()
-        st = s.stats()
-        per_gpu = []
-        for g in range(n_gpus):
-            gs = s.gpu_stats(g)
-            kms = gs["kernel_ms_sum"] / max(1, gs["launches"])
-            per_gpu.append({"gpu": g, "device": devices[g], "numa_node": s.gpu_option(g, "numa_node"), "launches": gs["launches"], "kernel_ms": round(kms, 3),
-                            "kernel_rate": round(gs["kangaroos"] * k.KNG_NB_RUN / (kms * 1e-3) / 1e6, 1)})
-        load = s.consumer_load()
-        host = s.host_stats()  # is the host keeping up?  (the threads are still alive: the kernel-side sums come after stop)
+      try:
+          power = sampler.stop().summary()
+          st = s.stats()
+          per_gpu = []
+          for g in range(n_gpus):
+              gs = s.gpu_stats(g)
+              kms = gs["kernel_ms_sum"] / max(1, gs["launches"])
+              per_gpu.append({"gpu": g, "device": devices[g], "numa_node": s.gpu_option(g, "numa_node"), "launches": gs["launches"], "kernel_ms": round(kms, 3),
+                              "kernel_rate": round(gs["kangaroos"] * k.KNG_NB_RUN / (kms * 1e-3) / 1e6, 1)})
+          load = s.consumer_load()
+          host = s.host_stats()  # is the host keeping up?  (the threads are still alive: the kernel-side sums come after stop)
 
-        class _Gpu0:  # the walk kernel that actually ran, from the engine of GPU 0 (every GPU gets the same options)
-            get_option = staticmethod(lambda key: s.gpu_option(0, key))
+          class _Gpu0:  # the walk kernel that actually ran, from the engine of GPU 0 (every GPU gets the same options)
+              get_option = staticmethod(lambda key: s.gpu_option(0, key))
 
-        kernel, group = _kernel_name(_Gpu0), s.gpu_option(0, "group")
-        aud = None
-        try:  # whole-run audit on the devices, outside the clock: every kangaroo of every herd and every table entry
-            aud = s.audit(True)
-        except Exception as e:  # noqa: BLE001
-            aud = {"error": str(e)}
-        s.stop()
-        after = s.host_stats()
-        for key in ("consumer_cpu_s", "consumer_runq_s", "consumer_busy_s", "consumer_nvcsw", "consumer_nivcsw"):
-            host[key] = after[key]
-        s.close()
-        assert all(p["launches"] == args.steps for p in per_gpu), per_gpu
-        jumps = n_gpus * n * k.KNG_NB_RUN * args.steps
-        kms = float(np.mean([p["kernel_ms"] for p in per_gpu]))
-        out = {
-            "metric": "kangaroo jumps/sec (MK/s)", "value": round(jumps / elapsed / 1e6, 2), "unit": "MK/s", "n_gpus": n_gpus,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {
-                "workload": f"80-bit range single key, auto DP {dp} (population of {n_gpus} GPUs), herd {gx}x{gy}x128 = 2^{np.log2(n):.0f} "
-                            f"kangaroos/GPU, {k.KNG_NB_RUN} jumps/launch",
-                "range_power": RANGE_POWER, "dp": dp, "grid": [gx, gy], "kangaroos_per_gpu": n, "device": info["name"], "arch": info["arch"],
-                "parallelism": f"independent herds x{n_gpus}: one process, a host thread per GPU, ONE shared host DP table, no collective",
-                "dps_per_step": round(st["dps"] / args.steps, 1), "dps_lost": st["dps_lost"], "table_consumers": len(load),
-                "what_is_timed": "kngs_start .. every GPU finished its K launches AND every distinguished point is in the table",
-            },
-            "per_gpu": per_gpu,
-            "power": {"timed_region": power},  # per device: package power, GFX clock (rocm_smi index = HIP index assumed)
-            # the N-GPU line diagnoses itself: a host that cannot keep up shows here (late_launches > 0, host_ms_max above the
-            # kernel time, consumers near 100 % busy or waiting for CPUs) before it shows as value < kernel_rate_sum
-            "host": dict(host, points_per_s_offered=round(st["dps"] / elapsed / 1e6, 2), points_unit="M points/s",
-                         cpu_ns_per_point=round((host.get("consumer_cpu_s") or 0) / max(1, st["dps"]) * 1e9, 1)),
-            "audit": aud,
-            "kernel_rate_sum": round(sum(p["kernel_rate"] for p in per_gpu), 1),
-            "roofline": _roofline(kernel, kms, n, k.KNG_NB_RUN, group, note="per GPU, mean over GPUs"),
-        }
-        out["config"]["control_plane"] = f"{ranks.backend} (CPU): no collective kernel on a measured GPU"
+          kernel, group = _kernel_name(_Gpu0), s.gpu_option(0, "group")
+          aud = None
+          try:  # whole-run audit on the devices, outside the clock: every kangaroo of every herd and every table entry
+              aud = s.audit(True)
+          except Exception as e:  # noqa: BLE001
+              aud = {"error": str(e)}
+          s.stop()
+          after = s.host_stats()
+          for key in ("consumer_cpu_s", "consumer_runq_s", "consumer_busy_s", "consumer_nvcsw", "consumer_nivcsw"):
+              host[key] = after[key]
+          s.close()
+          short = [p for p in per_gpu if p["launches"] != args.steps]
+          jumps = n_gpus * n * k.KNG_NB_RUN * args.steps
+          kms = float(np.mean([p["kernel_ms"] for p in per_gpu]))
+          out = {
+              "metric": "kangaroo jumps/sec (MK/s)", "value": round(jumps / elapsed / 1e6, 2), "unit": "MK/s", "n_gpus": n_gpus,
+              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+              "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+              "config": {
+                  "workload": f"80-bit range single key, auto DP {dp} (population of {n_gpus} GPUs), herd {gx}x{gy}x128 = 2^{np.log2(n):.0f} "
+                              f"kangaroos/GPU, {k.KNG_NB_RUN} jumps/launch",
+                  "range_power": RANGE_POWER, "dp": dp, "grid": [gx, gy], "kangaroos_per_gpu": n, "device": info["name"], "arch": info["arch"],
+                  "parallelism": f"independent herds x{n_gpus}: one process, a host thread per GPU, ONE shared host DP table, no collective",
+                  "dps_per_step": round(st["dps"] / args.steps, 1), "dps_lost": st["dps_lost"], "table_consumers": len(load),
+                  "what_is_timed": "kngs_start .. every GPU finished its K launches AND every distinguished point is in the table",
+              },
+              "per_gpu": per_gpu,
+              "power": {"timed_region": power},  # per device: package power, GFX clock; HIP index -> rocm_smi index by PCI address (telemetry.map_devices)
+              # the N-GPU line diagnoses itself: a host that cannot keep up shows here (late_launches > 0, host_ms_max above the
+              # kernel time, consumers near 100 % busy or waiting for CPUs) before it shows as value < kernel_rate_sum
+              "host": dict(host, points_per_s_offered=round(st["dps"] / elapsed / 1e6, 2), points_unit="M points/s",
+                           cpu_ns_per_point=round((host.get("consumer_cpu_s") or 0) / max(1, st["dps"]) * 1e9, 1)),
+              "audit": aud,
+              "kernel_rate_sum": round(sum(p["kernel_rate"] for p in per_gpu), 1),
+              "roofline": _roofline(kernel, kms, n, k.KNG_NB_RUN, group, note="per GPU, mean over GPUs"),
+          }
+          if short:  # the line still appears, and says it is not a valid measurement
+              out["error"] = f"{len(short)} GPU(s) did not finish their {args.steps} launches: {short}"
+          out["config"]["control_plane"] = f"{ranks.backend} (CPU): no collective kernel on a measured GPU"
+      except BaseException as e:  # noqa: BLE001  -- the driver expects ONE line from rank 0 whatever went wrong after the timed region
+        import traceback
+
+        log(traceback.format_exc())
+        out = {"metric": "kangaroo jumps/sec (MK/s)", "value": None, "unit": "MK/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+               "higher_is_better": True, "scaling": "weak", "error": f"post-processing failed: {e!r}",
+               "elapsed_s": round(elapsed, 4) if isinstance(elapsed, float) else None}
     ranks.close()
     if out is not None:
         print(json.dumps(out), flush=True)

@@ -61,6 +61,11 @@ int kng_device_info(int dev, char *name, size_t name_cap, int *cu_count, uint64_
 /* NUMA node of the host the device hangs off (sysfs numa_node of its PCI address), or -1 when unknown: a host that drives
  * several GPUs (Kangaroo.cpp:1041-1047, one thread per GPU) keeps each GPU's thread and its pinned DP buffers on that node */
 int kng_device_numa_node(int dev);
+/* the two halves of that, usable on their own: the device's PCI address ("0000:c3:00.0", lower case) -- what ties a HIP
+ * device index to the same card in rocm_smi / amd-smi, whose indices need not agree with HIP's under HIP_VISIBLE_DEVICES --
+ * and the sysfs lookup of an address (no device needed; KNG_SYSFS_ROOT replaces "/sys") */
+int kng_device_pci_bdf(int dev, char *bdf, size_t cap);
+int kng_numa_node_of_bdf(const char *bdf);
 /* free / total device memory right now (hipMemGetInfo): lets a host that re-creates its engine once per key
  * (Kangaroo.cpp:1021-1075, ctor :523, `delete gpu` :634) check that a create / destroy cycle gives everything back */
 int kng_device_free_bytes(int dev, uint64_t *free_bytes, uint64_t *total_bytes);

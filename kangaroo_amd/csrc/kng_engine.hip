@@ -908,20 +908,38 @@ int kng_device_info(int dev, char *name, size_t name_cap, int *cu_count, uint64_
     return KNG_OK;
 }
 
-int kng_device_numa_node(int dev) {
-    if (dev < 0 || dev >= kng_device_count()) return -1;
-    char bdf[64] = {0};
-    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, dev) != hipSuccess) return -1;
+// sysfs numa_node of a PCI address ("0000:C3:00.0", any case), -1 when unknown.  No device needed: the parsing is tested
+// against a made-up tree (KNG_SYSFS_ROOT replaces "/sys").
+int kng_numa_node_of_bdf(const char *bdf_in) {
+    if (!bdf_in || !*bdf_in || strlen(bdf_in) >= 64) return -1;
+    char bdf[64];
+    snprintf(bdf, sizeof bdf, "%s", bdf_in);
     for (char *c = bdf; *c; c++)
         if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a'); // sysfs spells the address in lower case
-    char path[160];
-    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    const char *root = getenv("KNG_SYSFS_ROOT");
+    char path[4200];
+    snprintf(path, sizeof path, "%s/bus/pci/devices/%s/numa_node", root && *root ? root : "/sys", bdf);
     FILE *f = fopen(path, "r");
     if (!f) return -1;
     int node = -1;
-    if (fscanf(f, "%d", &node) != 1) node = -1;
+    if (fscanf(f, "%d", &node) != 1 || node < 0) node = -1; // "-1" = the platform does not say
     fclose(f);
     return node;
+}
+
+int kng_device_pci_bdf(int dev, char *bdf, size_t cap) {
+    if (!bdf || cap < 13) return fail(KNG_E_ARG, "bdf buffer too small");
+    if (dev < 0 || dev >= kng_device_count()) return fail(KNG_E_NODEVICE, "invalid device %d", dev);
+    HIP_TRY(hipDeviceGetPCIBusId(bdf, (int)cap, dev));
+    for (char *c = bdf; *c; c++)
+        if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    return KNG_OK;
+}
+
+int kng_device_numa_node(int dev) {
+    char bdf[64] = {0};
+    if (kng_device_pci_bdf(dev, bdf, sizeof bdf) != KNG_OK) return -1;
+    return kng_numa_node_of_bdf(bdf);
 }
 
 int kng_device_free_bytes(int dev, uint64_t *free_bytes, uint64_t *total_bytes) {

@@ -358,7 +358,9 @@ class GPUEngine:
         bad = C.c_uint64(0)
         idx = np.zeros(max(cap, 1), np.uint64)
         _check(self._L.kng_audit_herd(self._h, C.byref(bad), idx.ctypes.data, cap))
-        return int(bad.value), [int(v) for v in idx[: min(cap, bad.value)]]
+        # the device keeps at most 1024 indices per audit launch (2^21 kangaroos each): never hand back the zero padding
+        kept = 1024 * max(1, -(-self.nbKangaroo // (1 << 21)))
+        return int(bad.value), [int(v) for v in idx[: min(cap, bad.value, kept)]]
 
     def audit_points(self, records: np.ndarray, cap: int = 16):
         """(mismatches, first mismatching positions): records of RECORD_DTYPE (reserved = 0: full x, 1: table-entry bits)."""
@@ -366,7 +368,8 @@ class GPUEngine:
         bad = C.c_uint64(0)
         idx = np.zeros(max(cap, 1), np.uint64)
         _check(self._L.kng_audit_points(self._h, records.ctypes.data, len(records), C.byref(bad), idx.ctypes.data, cap))
-        return int(bad.value), [int(v) for v in idx[: min(cap, bad.value)]]
+        kept = 1024 * max(1, -(-len(records) // (1 << 21)))
+        return int(bad.value), [int(v) for v in idx[: min(cap, bad.value, kept)]]
 
     def drain_records(self) -> np.ndarray:
         """kng_drain_view: the 64-byte records of the most recently waited launch, copied out of the landing buffer."""

@@ -2,13 +2,16 @@
 #include "kng_solver.h"
 
 #include <sched.h>
+#include <unistd.h>
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
 #include <sys/mman.h>
 #include <sys/resource.h>
 
+#include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <condition_variable>
 #include <cstdarg>
@@ -191,6 +194,7 @@ struct Worker {
 
 struct kngs_solver {
     kngs_config cfg;
+    unsigned instance = 0; // how many solvers this process created before this one (rotates KNGS_PIN=core's choice of cores)
     // derived (InitRange / InitSearchKey / CreateJumpTable)
     int range_power = 0, dp = 0;
     U256 wild_offset{};
@@ -272,51 +276,83 @@ void request_reset(kngs_solver *s, const DpMsg &m) {
 
 // ---- NUMA placement of the table threads.  The table grows by gigabytes per second and every insertion is a handful of
 // dependent cache misses: a consumer that wanders between sockets (or whose arenas were first touched on the other one)
-// pays the remote latency on each of them.  Consumer i of n is confined to the CPUs of node i * nodes / n, so that the
-// memory its arenas take from the OS (first touch) stays local for the whole run.  No libnuma: sysfs + sched_setaffinity.
+// pays the remote latency on each of them.  Consumer i of n is confined to the CPUs of the i*nodes/n-th node that has CPUs
+// this process may use, so that the memory its arenas take from the OS (first touch) stays local for the whole run.
+// No libnuma: sysfs + sched_setaffinity.  KNG_SYSFS_ROOT replaces "/sys" (tests run against a made-up tree).
+std::string sysfs_root() {
+    const char *e = getenv("KNG_SYSFS_ROOT");
+    return e && *e ? std::string(e) : std::string("/sys");
+}
+
+// "0-63,128-191" -> the CPUs of the list that are also in `allowed`
+int parse_cpulist(const char *text, const cpu_set_t &allowed, cpu_set_t *out) {
+    CPU_ZERO(out);
+    int n_set = 0;
+    for (const char *p = text; *p;) {
+        char *e;
+        const long a = strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        p = e;
+        if (*p == '-') {
+            b = strtol(p + 1, &e, 10);
+            p = e;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (c >= 0 && CPU_ISSET((int)c, &allowed) && !CPU_ISSET((int)c, out)) {
+                CPU_SET((int)c, out);
+                n_set++;
+            }
+        if (*p == ',') p++;
+    }
+    return n_set;
+}
+
+// CPU sets INDEXED BY THE REAL NODE ID: entry k is node k's CPUs cut by this process's affinity mask -- empty when the node
+// does not exist, has no CPUs (memory-only nodes), or none of its CPUs is allowed (numactl, a cpuset).  Node ids may be
+// sparse; the scan covers every id up to the highest directory present (a compacted list indexed with sysfs's
+// numa_node put GPU threads and their pinned rings on the wrong node).
 std::vector<cpu_set_t> numa_node_cpus() {
     std::vector<cpu_set_t> nodes;
     cpu_set_t allowed;
     CPU_ZERO(&allowed);
     if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return nodes;
-    for (int node = 0; node < 64; node++) {
-        char path[96];
-        snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    const std::string root = sysfs_root();
+    int missing = 0;
+    for (int node = 0; node < 1024 && missing < 64; node++) {
+        char path[4200];
+        snprintf(path, sizeof path, "%s/devices/system/node/node%d/cpulist", root.c_str(), node);
         FILE *f = fopen(path, "r");
-        if (!f) break;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (!f) {
+            missing++;
+            continue;
+        }
+        missing = 0;
         char buf[4096];
         const bool ok = fgets(buf, sizeof buf, f) != nullptr;
         fclose(f);
-        if (!ok) break;
-        cpu_set_t set;
-        CPU_ZERO(&set);
-        int n_set = 0;
-        for (char *p = buf; *p;) { // "0-63,128-191"
-            char *e;
-            const long a = strtol(p, &e, 10);
-            if (e == p) break;
-            long b = a;
-            p = e;
-            if (*p == '-') b = strtol(p + 1, &p, 10);
-            for (long c = a; c <= b && c < CPU_SETSIZE; c++)
-                if (CPU_ISSET((int)c, &allowed)) {
-                    CPU_SET((int)c, &set);
-                    n_set++;
-                }
-            if (*p == ',') p++;
-        }
-        if (n_set) nodes.push_back(set);
+        if (ok) (void)parse_cpulist(buf, allowed, &set);
+        nodes.resize((size_t)node + 1);
+        nodes[(size_t)node] = set;
     }
+    // (entries the resize created for ids that have no directory are zero-initialised cpu_set_t: empty sets)
     return nodes;
+}
+
+inline bool node_usable(const std::vector<cpu_set_t> &nodes, int id) {
+    return id >= 0 && (size_t)id < nodes.size() && CPU_COUNT(&nodes[(size_t)id]) > 0;
 }
 
 // one logical CPU per physical core of `set`: the lowest-numbered hardware thread of each core
 std::vector<int> primary_cpus(const cpu_set_t &set) {
     std::vector<int> out;
+    const std::string root = sysfs_root();
     for (int cpu = 0; cpu < CPU_SETSIZE; cpu++) {
         if (!CPU_ISSET(cpu, &set)) continue;
-        char path[128];
-        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
+        char path[4200];
+        snprintf(path, sizeof path, "%s/devices/system/cpu/cpu%d/topology/thread_siblings_list", root.c_str(), cpu);
         int first = cpu;
         if (FILE *f = fopen(path, "r")) {
             if (fscanf(f, "%d", &first) != 1) first = cpu;
@@ -327,8 +363,80 @@ std::vector<int> primary_cpus(const cpu_set_t &set) {
     return out;
 }
 
+// Where each of `nc` table threads may run.  Default ("node"): the whole CPU set of its node -- the scheduler spreads the
+// threads, they can move away from a CPU a GPU thread or another solver's table thread sits on, memory stays local.
+// KNGS_PIN=core: ONE physical core per thread, spread evenly over the node's cores (hence over its L3 slices); on the 16-CPU
+// GPU box that took eight flat-out feeders from 159 to 174 M points/s (profiles/r04_dp_host_*.txt) -- and it is opt-in because
+// the choice is blind to everything else on the machine: a pinned thread cannot leave a CPU that something else keeps busy
+// (every solver instance of a host, or two Solver objects in one process, used to pick the SAME cores; `salt`
+// -- instance count + process id -- now rotates the choice, which helps between instances, not against strangers).
+// A machine with one usable node is left alone in "node" mode (confining threads to "all CPUs" says nothing).
+struct Placement {
+    bool pin = false;
+    int node = -1;
+    cpu_set_t cpus;
+};
+std::vector<Placement> plan_consumers(const std::vector<cpu_set_t> &nodes, int nc, bool per_core, unsigned salt) {
+    std::vector<Placement> plan((size_t)(nc > 0 ? nc : 0));
+    for (Placement &p : plan) CPU_ZERO(&p.cpus);
+    std::vector<int> usable;
+    for (size_t k = 0; k < nodes.size(); k++)
+        if (CPU_COUNT(&nodes[k]) > 0) usable.push_back((int)k);
+    if (usable.empty() || nc <= 0) return plan;
+    for (size_t u = 0; u < usable.size(); u++) {
+        const cpu_set_t &set = nodes[(size_t)usable[u]];
+        std::vector<int> mine; // consumers of this node
+        for (int c = 0; c < nc; c++)
+            if ((size_t)c * usable.size() / (size_t)nc == u) mine.push_back(c);
+        const std::vector<int> cores = per_core ? primary_cpus(set) : std::vector<int>();
+        for (size_t j = 0; j < mine.size(); j++) {
+            Placement &p = plan[(size_t)mine[j]];
+            p.node = usable[u];
+            // one core each only where cores abound: twice as many as threads on a single-node machine (the GPU threads and
+            // everybody else need somewhere to go), as many as threads on a node of several
+            if (per_core && cores.size() >= mine.size() * (usable.size() > 1 ? 1 : 2)) {
+                p.pin = true;
+                const size_t stride = cores.size() / mine.size();
+                CPU_SET(cores[(j * stride + salt % stride) % cores.size()], &p.cpus);
+            } else if (usable.size() > 1) {
+                p.pin = true;
+                p.cpus = set;
+            }
+        }
+    }
+    return plan;
+}
+
+std::atomic<unsigned> g_solver_instances{0};
+std::atomic<uint64_t> g_pin_failures{0};
+
+// confine the calling thread; a refusal (the mask changed under us, a cpuset without these CPUs) is counted and reported
+// once -- the thread then simply runs wherever it is allowed to
+bool pin_this_thread(const cpu_set_t &cpus, const char *who) {
+    if (CPU_COUNT(&cpus) > 0 && sched_setaffinity(0, sizeof cpus, &cpus) == 0) return true;
+    if (g_pin_failures.fetch_add(1) == 0)
+        fprintf(stderr, "kangaroo host: could not confine a %s thread to its CPUs (%s); it runs unconfined\n", who,
+                CPU_COUNT(&cpus) > 0 ? strerror(errno) : "empty CPU set");
+    return false;
+}
+
+std::string cpuset_text(const cpu_set_t &set) {
+    std::string out;
+    for (int c = 0; c < CPU_SETSIZE; c++) {
+        if (!CPU_ISSET(c, &set)) continue;
+        int e = c;
+        while (e + 1 < CPU_SETSIZE && CPU_ISSET(e + 1, &set)) e++;
+        char buf[48];
+        if (e > c) snprintf(buf, sizeof buf, "%s%d-%d", out.empty() ? "" : ",", c, e);
+        else snprintf(buf, sizeof buf, "%s%d", out.empty() ? "" : ",", c);
+        out += buf;
+        c = e;
+    }
+    return out;
+}
+
 void consumer_main(kngs_solver *s, Consumer *c) {
-    if (c->pin) (void)sched_setaffinity(0, sizeof c->cpus, &c->cpus); // (0 = the calling thread)
+    if (c->pin) (void)pin_this_thread(c->cpus, "table");
     struct AtExit {
         Consumer *c;
         ~AtExit() {
@@ -529,7 +637,7 @@ void worker_main(kngs_solver *s, Worker *w) {
         s->ctl_cv.notify_all();
     };
 
-    if (w->pin) (void)sched_setaffinity(0, sizeof w->cpus, &w->cpus); // next to its GPU: the ring it reads was written over that node's PCIe root
+    if (w->pin) (void)pin_this_thread(w->cpus, "GPU"); // next to its GPU: the ring it reads was written over that node's PCIe root
     if (kng_launch(w->eng) != KNG_OK) return bail(std::string("kng_launch: ") + kng_last_error());
     Clock::time_point host_t0{};
     bool have_host_t0 = false;
@@ -656,6 +764,7 @@ int kngs_create(const kngs_config *cfg, kngs_solver **out) {
     if (!kngh_on_curve(cfg->key_x, cfg->key_y)) return fail("the public key does not lie on the curve");
     kngs_solver *s = new kngs_solver();
     s->cfg = *cfg;
+    s->instance = g_solver_instances.fetch_add(1);
     // InitRange (Kangaroo.cpp:877-890)
     const U256 width = sub256(cfg->range_end, cfg->range_start);
     s->range_power = bit_length(width);
@@ -740,34 +849,22 @@ double effective_cpus();
 void start_consumers(kngs_solver *s, int nc) {
     for (int c = 0; c < nc; c++) s->consumers.push_back(new Consumer());
     const std::vector<cpu_set_t> nodes = (s->cfg.flags & KNGS_FLAG_NO_PIN) ? std::vector<cpu_set_t>() : numa_node_cpus();
-    if (!nodes.empty()) {
-        // one physical core per consumer, spread evenly over the node's cores (hence over its L3 slices): left to itself the
-        // scheduler wakes a table thread next to the GPU thread that fed it, and a dozen of them end up sharing a few cores
-        // and one L3 while the rest of the socket idles (profiles/r04_dp_host_bigregions.txt: 16 threads 159 M points/s,
-        // 32 threads 107).  A node with fewer cores than consumers gets its whole CPU set instead.
-        const char *mode = getenv("KNGS_PIN");
-        const bool per_core = !mode || std::string(mode) != "node";
-        for (size_t nd = 0; nd < nodes.size(); nd++) {
-            std::vector<int> mine; // consumers of this node
-            for (int c = 0; c < nc; c++)
-                if ((size_t)c * nodes.size() / (size_t)nc == nd) mine.push_back(c);
-            std::vector<int> cores = per_core ? primary_cpus(nodes[nd]) : std::vector<int>();
-            for (size_t j = 0; j < mine.size(); j++) {
-                Consumer *cs = s->consumers[(size_t)mine[j]];
-                cs->pin = true;
-                // (a single-node machine is pinned too -- the crowding has nothing to do with NUMA -- but only where cores abound)
-                if (cores.size() >= mine.size() * (nodes.size() > 1 ? 1 : 2)) {
-                    CPU_ZERO(&cs->cpus);
-                    CPU_SET(cores[j * cores.size() / mine.size()], &cs->cpus);
-                } else if (nodes.size() > 1) {
-                    cs->cpus = nodes[nd];
-                } else {
-                    cs->pin = false;
-                }
-            }
+    const char *mode = getenv("KNGS_PIN");
+    const bool per_core = mode && std::string(mode) == "core";
+    const unsigned salt = s->instance + (unsigned)getpid();
+    const std::vector<Placement> plan = plan_consumers(nodes, nc, per_core, salt);
+    int used_nodes = 0;
+    {
+        std::vector<int> seen;
+        for (int c = 0; c < nc; c++) {
+            Consumer *cs = s->consumers[(size_t)c];
+            cs->pin = plan[(size_t)c].pin;
+            cs->cpus = plan[(size_t)c].cpus;
+            if (plan[(size_t)c].node >= 0 && std::find(seen.begin(), seen.end(), plan[(size_t)c].node) == seen.end()) seen.push_back(plan[(size_t)c].node);
         }
+        used_nodes = (int)seen.size();
     }
-    s->numa_nodes = (int)nodes.size();
+    s->numa_nodes = used_nodes;
     s->cpus = effective_cpus();
     { // the first launch must not pay for the pool: one chunk per (GPU thread, consumer) pair, touched once
         std::vector<Chunk *> warm;
@@ -907,10 +1004,14 @@ int kngs_prepare(kngs_solver *s) {
         cpu_set_t before;
         bool moved = false;
         w->numa_node = kng_device_numa_node(w->dev);
-        if (nodes.size() > 1 && w->numa_node >= 0 && (size_t)w->numa_node < nodes.size() && sched_getaffinity(0, sizeof before, &before) == 0) {
+        // (looked up BY NODE ID; a node none of whose CPUs this process may use -- numactl, a cpuset -- pins nothing)
+        int usable_nodes = 0;
+        for (size_t k = 0; k < nodes.size(); k++) usable_nodes += CPU_COUNT(&nodes[k]) > 0;
+        if (usable_nodes > 1 && node_usable(nodes, w->numa_node) && sched_getaffinity(0, sizeof before, &before) == 0) {
             w->pin = true;
             w->cpus = nodes[(size_t)w->numa_node];
-            moved = sched_setaffinity(0, sizeof w->cpus, &w->cpus) == 0;
+            moved = pin_this_thread(w->cpus, "GPU");
+            if (!moved) w->pin = false;
         }
         const int crc = kng_create(w->dev, w->grid_x, w->grid_y, s->cfg.max_found, &w->eng);
         if (moved) (void)sched_setaffinity(0, sizeof before, &before);
@@ -1067,8 +1168,45 @@ int kngs_host_stats(const kngs_solver *s, kngs_host_stats_t *out) {
     out->run_seconds = run_s;
     out->numa_nodes = (uint32_t)s->numa_nodes;
     out->effective_cpus = s->cpus > 0 ? s->cpus : effective_cpus();
+    out->pin_failures = g_pin_failures.load();
     return 0;
 }
+
+// ---- placement, inspectable without a GPU (tests run these against a made-up sysfs tree, KNG_SYSFS_ROOT) ----
+int kngs_plan_placement(int n_consumers, int per_core, unsigned salt, char *out, size_t cap) {
+    if (!out || cap == 0 || n_consumers < 0) return fail("bad argument");
+    const std::vector<cpu_set_t> nodes = numa_node_cpus();
+    const std::vector<Placement> plan = plan_consumers(nodes, n_consumers, per_core != 0, salt);
+    std::string text;
+    for (size_t k = 0; k < nodes.size(); k++) text += "node " + std::to_string(k) + ": " + (CPU_COUNT(&nodes[k]) ? cpuset_text(nodes[k]) : std::string("-")) + "\n";
+    for (size_t c = 0; c < plan.size(); c++)
+        text += "consumer " + std::to_string(c) + ": node " + std::to_string(plan[c].node) + " " + (plan[c].pin ? "cpus " + cpuset_text(plan[c].cpus) : std::string("unconfined")) + "\n";
+    snprintf(out, cap, "%s", text.c_str());
+    return (int)nodes.size();
+}
+
+int kngs_gpu_thread_cpus(int device_numa_node, char *out, size_t cap) {
+    if (!out || cap == 0) return fail("bad argument");
+    const std::vector<cpu_set_t> nodes = numa_node_cpus();
+    int usable_nodes = 0;
+    for (size_t k = 0; k < nodes.size(); k++) usable_nodes += CPU_COUNT(&nodes[k]) > 0;
+    const bool pin = usable_nodes > 1 && node_usable(nodes, device_numa_node);
+    snprintf(out, cap, "%s", pin ? cpuset_text(nodes[(size_t)device_numa_node]).c_str() : "unconfined");
+    return pin ? 1 : 0;
+}
+
+int kngs_try_pin(const char *cpulist) {
+    cpu_set_t all, want, before;
+    CPU_ZERO(&all);
+    for (int c = 0; c < CPU_SETSIZE; c++) CPU_SET(c, &all);
+    (void)parse_cpulist(cpulist ? cpulist : "", all, &want);
+    if (sched_getaffinity(0, sizeof before, &before) != 0) return -1;
+    const bool ok = pin_this_thread(want, "test");
+    (void)sched_setaffinity(0, sizeof before, &before);
+    return ok ? 1 : 0;
+}
+
+uint64_t kngs_pin_failures(void) { return g_pin_failures.load(); }
 
 const kngt_table *kngs_table(const kngs_solver *s) { return s ? s->table : nullptr; }
 

@@ -23,6 +23,7 @@
 #ifndef KNG_SOLVER_H
 #define KNG_SOLVER_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -132,6 +133,7 @@ typedef struct kngs_host_stats_t {
     double consumer_cpu_s, consumer_runq_s, consumer_busy_s;
     uint64_t consumer_nvcsw, consumer_nivcsw;
     double effective_cpus; /* CPUs the process may use: hardware threads cut by affinity and the cgroup quota (sizes the default consumer count) */
+    uint64_t pin_failures; /* threads of this process that could not be confined to the CPUs planned for them (they ran unconfined) */
 } kngs_host_stats_t;
 int kngs_host_stats(const kngs_solver *s, kngs_host_stats_t *out);
 /* points each consumer thread has taken off its queue; returns the number of consumers */
@@ -148,6 +150,18 @@ int kngs_drained(kngs_solver *s, double seconds);
 /* the solver's table, read-only (tests; exact only while no point is in flight) */
 struct kngt_table;
 const struct kngt_table *kngs_table(const kngs_solver *s);
+/* ---- thread placement, inspectable without a GPU.  Node CPU sets come from <root>/devices/system/node/nodeK/cpulist cut by
+ * the caller's affinity mask, indexed by the REAL node id (sparse ids and nodes without usable CPUs give empty sets);
+ * KNG_SYSFS_ROOT replaces "/sys".  kngs_plan_placement writes one "node K: <cpulist or ->" line per node id and one
+ * "consumer C: node K cpus <list>|unconfined" line per table thread (per_core = what KNGS_PIN=core selects; the default
+ * confines a table thread to its node, and not at all on a one-node machine) and returns the number of node ids.
+ * kngs_gpu_thread_cpus: where the host thread (and the pinned rings) of a GPU on `device_numa_node` would be confined
+ * (returns 1 + the list, or 0 + "unconfined").  kngs_try_pin: 1 when the calling thread could be confined to `cpulist`
+ * (its mask is restored), 0 when the kernel refused -- counted in kngs_pin_failures / kngs_host_stats_t.pin_failures. */
+int kngs_plan_placement(int n_consumers, int per_core, unsigned salt, char *out, size_t cap);
+int kngs_gpu_thread_cpus(int device_numa_node, char *out, size_t cap);
+int kngs_try_pin(const char *cpulist);
+uint64_t kngs_pin_failures(void);
 const char *kngs_last_error(void);
 
 #ifdef __cplusplus

@@ -55,7 +55,8 @@ class _HostStats(C.Structure):
                 ("late_launches", C.c_uint64), ("queue_high_points", C.c_uint64), ("consumer_busy_max", C.c_double),
                 ("consumer_busy_mean", C.c_double), ("run_seconds", C.c_double), ("consumers", C.c_uint32), ("numa_nodes", C.c_uint32),
                 ("consumer_cpu_s", C.c_double), ("consumer_runq_s", C.c_double), ("consumer_busy_s", C.c_double),
-                ("consumer_nvcsw", C.c_uint64), ("consumer_nivcsw", C.c_uint64), ("effective_cpus", C.c_double)]
+                ("consumer_nvcsw", C.c_uint64), ("consumer_nivcsw", C.c_uint64), ("effective_cpus", C.c_double),
+                ("pin_failures", C.c_uint64)]
 
 
 class _AuditResult(C.Structure):

@@ -303,6 +303,34 @@ def test_bench_multi_gpu_mode_on_one_device(sv):
     assert line["config"]["dps_lost"] == 0
 
 
+def test_bench_eight_engines_with_fewer_cpus_than_threads(sv):
+    """`bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0` confined to four CPUs (taskset): eight GPU threads + table threads on four
+    CPUs is what a small CPU quota on an 8-GPU lease looks like.  The line must still appear, complete, with every launch
+    done, no point lost, the table threads sized to the CPUs there are, each device row tied to rocm_smi by PCI address, and
+    a clean whole-run audit."""
+    import json
+    import shutil
+    import sys
+
+    if not shutil.which("taskset"):
+        pytest.skip("no taskset")
+    cpus = sorted(os.sched_getaffinity(0))[:4]
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run(["taskset", "-c", ",".join(map(str, cpus)), sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--devices",
+                          "0,0,0,0,0,0,0,0", "--steps", "4", "--warmup", "1", "--grid", "32,128"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert "error" not in line, line.get("error")
+    assert line["n_gpus"] == 8 and [p["launches"] for p in line["per_gpu"]] == [4] * 8
+    assert line["config"]["dps_lost"] == 0 and line["host"]["effective_cpus"] <= 4.0
+    assert 1 <= line["config"]["table_consumers"] <= 4
+    assert line["host"]["pin_failures"] == 0
+    assert line["audit"]["kangaroo_mismatches"] == 0 and line["audit"]["table_mismatches"] == 0
+    dev = line["power"]["timed_region"]
+    if dev.get("available"):
+        assert dev["devices"][0]["smi_mapping"] in ("pci", "index (assumed)")
+
+
 def test_restore_into_a_different_number_of_gpus(sv, tmp_path, orc):
     """FetchWalks (Kangaroo.cpp:646-668): a work file with fewer kangaroos than the GPUs hold restores what it has and the
     rest is created; one with more fills the herd and the surplus stays in the file.  The restored kangaroos are the
