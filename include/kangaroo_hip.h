@@ -193,8 +193,10 @@ int kng_last_kernel_ms(const kng_engine *h, float *ms);
  *   "lanes"  alternatively the lane count itself (multiple of 64, need not divide the herd: waves then
  *            walk ceil or floor of herd/lanes kangaroos)
  *   "block"  threads per workgroup (multiple of 64)
- *   "share"  waves that share one modular inversion per jump: 8 = the eight waves of a 512-thread block, i.e. one
- *            inversion per CU -- the only form left (rounds 1-3 also carried 1 = every wave inverts for itself)
+ *   "share"  waves that share one modular inversion per jump: 8 = the eight waves of a 512-thread block, i.e. one inversion
+ *            per CU; 4 = 256-thread blocks, one wave per SIMD, for herds too small to give every CU a 512-thread block (their
+ *            launches are 64 serial inversions: latency, not throughput); -1 (default) = 4 when lanes < 512 x CUs, else 8.
+ *            Reads back what a launch uses (8 or 4).  (Rounds 1-3 also carried 1 = every wave inverts for itself.)
  *   "dsplit" -1 (default): stream only the low word of the 128-bit distances through HBM when every jump
  *            distance given to kng_set_params is below 2^58 (ranges up to 115 bits; 2^50 with "asm" 0): the high word
  *            is then updated by an L2 atomic of the lanes whose low word carried;

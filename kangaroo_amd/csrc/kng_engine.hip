@@ -352,6 +352,44 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
             __syncthreads();
             if (w >= 4) inv = get(w);
             if (G == 0) continue;
+        } else if (SHARE == 4) {
+            // Small herds (fewer lanes than 512 x CUs): 256-thread blocks, one wave per SIMD, so that EVERY CU gets a block
+            // -- a launch of such a herd is 64 serial inversions plus 64 walks of one kangaroo per lane, nothing overlaps, and
+            // 512-thread blocks would leave half the CUs idle while two waves share each SIMD of the others.  One tree level:
+            // waves 2, 3 hand their products to waves 0, 1; wave 0 multiplies the two pair products, inverts ONCE, walks back.
+            const uint32_t col = threadIdx.x & 63, w = threadIdx.x >> 6;
+            auto put = [&](uint32_t slot, const fe &v) {
+                xch[(2 * slot) * 64 + col] = make_ulonglong2(v.v[0], v.v[1]);
+                xch[(2 * slot + 1) * 64 + col] = make_ulonglong2(v.v[2], v.v[3]);
+            };
+            auto get = [&](uint32_t slot) -> fe {
+                const v16 b0 = xch[(2 * slot) * 64 + col], b1 = xch[(2 * slot + 1) * 64 + col];
+                return fe{{b0.x, b0.y, b1.x, b1.y}};
+            };
+            if (w >= 2) put(w, acc);
+            __syncthreads();
+            fe pb = fe_one(), pre = fe_one(), i = fe_one();
+            if (w < 2) {
+                pb = get(w + 2);
+                pre = fe_mul(acc, pb);
+                if (w) put(1, pre);
+            }
+            __syncthreads();
+            if (w == 0) {
+                const fe q1 = get(1);
+                fe t = fe_inv(fe_mul(pre, q1));
+                put(1, fe_mul(t, pre)); // 1/q1
+                i = fe_mul(t, q1);      // 1/pre of wave 0
+            }
+            __syncthreads();
+            if (w == 1) i = get(1);
+            if (w < 2) {
+                put(w + 2, fe_mul(i, acc)); // 1/pb
+                inv = fe_mul(i, pb);        // 1/acc
+            }
+            __syncthreads();
+            if (w >= 2) inv = get(w);
+            if (G == 0) continue;
         } else {
             inv = fe_inv(acc);
         }
@@ -430,9 +468,9 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
 // no barrier).  SHARE = 8: 512-thread blocks, one inversion per CU.  (Round 2 also carried SHARE = 2, SHARE = 3 and two
 // non-template twins of <1,.>: share 3 lost at every herd size, profiles/r02_group_share_sweep.txt; share 2 loses to 8.)
 template <int SHARE, bool DSPLIT, bool ASM>
-__global__ void __launch_bounds__(SHARE == 1 ? 256 : 512) __attribute__((amdgpu_waves_per_eu(2, 2))) kng_walk_share_kernel(const WalkArgs a) {
+__global__ void __launch_bounds__(SHARE == 8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2, 2))) kng_walk_share_kernel(const WalkArgs a) {
     __shared__ uint64_t tab[JT_WORDS];
-    __shared__ v16 xch[SHARE == 8 ? 1024 : 1];
+    __shared__ v16 xch[SHARE == 8 ? 1024 : SHARE == 4 ? 512 : 1];
     for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
     __syncthreads();
     walk_body<SHARE, DSPLIT, ASM>(a, tab, xch);
@@ -740,7 +778,8 @@ struct kng_engine {
     int dsplit = -1;       // distance plane: -1 = low-word streaming when every jump distance < 2^50, 0 = never, 1 = whenever the table allows (high words all zero)
     bool dsplit_on = false; // decided by kng_set_params / the option
     uint64_t jd_max = 0;    // largest low word of the jump distances, UINT64_MAX when a high word is set
-    int share = 8;         // waves of a 512-thread block (= of a CU at the bench geometry) that share one inversion per jump
+    int share = -1;        // waves that share one inversion per jump: 8 (512-thread blocks, one inversion per CU), 4 (256-thread blocks), -1 = by herd size (kng_launch)
+    int share_used = 8;    // what the last launch ran with
     int use_asm = 1;       // the scheduled asm loop (kng_walk_asm.h) instead of the compiler-scheduled one; herds beyond 2^28 cannot
     WalkAsmArgs *asm_args = nullptr; // device: one block per DP buffer
     v16 *planes = nullptr; // 7 planes of n v16
@@ -1096,7 +1135,7 @@ int kng_set_option(kng_engine *h, const char *key, int64_t value) {
         h->dsplit = (int)value;
         decide_dsplit(h);
     } else if (k == "share") {
-        if (value != 8) return fail(KNG_E_ARG, "share must be 8 (one inversion per CU; the every-wave-inverts form of rounds 1-3 was removed)");
+        if (value != 8 && value != 4 && value != -1) return fail(KNG_E_ARG, "share must be 8 (one inversion per CU), 4 (one per 256-thread block) or -1 (by herd size); the every-wave-inverts form of rounds 1-3 was removed");
         h->share = (int)value;
     } else if (k == "dp_ring") {
         if (value < 0 || value > 1) return fail(KNG_E_ARG, "dp_ring must be 0 or 1");
@@ -1157,7 +1196,7 @@ int kng_get_option(const kng_engine *h, const char *key, int64_t *value) {
     else if (k == "block") *value = h->block;
     else if (k == "steps") *value = h->nsteps;
     else if (k == "lanes") *value = h->lanes;
-    else if (k == "share") *value = h->share;
+    else if (k == "share") *value = h->share == -1 ? ((uint64_t)h->lanes < (uint64_t)h->cu_count * 512 ? 4 : 8) : h->share;
     else if (k == "asm") *value = h->use_asm;
     else if (k == "dp_ring") *value = h->dp_ring;
     else if (k == "dsplit") *value = h->dsplit_on ? 1 : 0;
@@ -1427,12 +1466,22 @@ int kng_launch(kng_engine *h) {
     HIP_TRY(hipMemsetAsync(h->dp_count[s], 0, 8, h->walk)); // GPUEngine.cu:543 (+ the launch's exact-path exit counter)
     HIP_TRY(hipEventRecord(h->ev_start[s], h->walk));
     const bool ds = h->dsplit_on;
-    const dim3 grid2((h->lanes + 511) / 512);
+    // herds whose lanes do not give every CU a 512-thread block walk in 256-thread blocks (one inversion per four waves,
+    // one wave per SIMD, twice as many CUs busy): option "share" -1 (default) decides per herd, 8 / 4 force the form
+    const int share = h->share == -1 ? ((uint64_t)h->lanes < (uint64_t)h->cu_count * 512 ? 4 : 8) : h->share;
+    h->share_used = share;
+    const uint32_t bthreads = share == 8 ? 512 : 256;
+    const dim3 grid2((h->lanes + bthreads - 1) / bthreads);
 #define KNG_LAUNCH(SH, DS, AS, GRID, BLOCK) hipLaunchKernelGGL((kng_walk_share_kernel<SH, DS, AS>), GRID, dim3(BLOCK), 0, h->walk, a)
     // four instantiations: the scheduled loop for either distance layout, and the compiler-scheduled pair that serves herds
     // beyond 2^28 kangaroos (and is the exact path behind the scheduled loop).  Round 1-3's share = 1 family is gone.
-    if (h->use_asm) { if (ds) KNG_LAUNCH(8, true, true, grid2, 512); else KNG_LAUNCH(8, false, true, grid2, 512); }
-    else { if (ds) KNG_LAUNCH(8, true, false, grid2, 512); else KNG_LAUNCH(8, false, false, grid2, 512); }
+    if (share == 8) {
+        if (h->use_asm) { if (ds) KNG_LAUNCH(8, true, true, grid2, 512); else KNG_LAUNCH(8, false, true, grid2, 512); }
+        else { if (ds) KNG_LAUNCH(8, true, false, grid2, 512); else KNG_LAUNCH(8, false, false, grid2, 512); }
+    } else {
+        if (h->use_asm) { if (ds) KNG_LAUNCH(4, true, true, grid2, 256); else KNG_LAUNCH(4, false, true, grid2, 256); }
+        else { if (ds) KNG_LAUNCH(4, true, false, grid2, 256); else KNG_LAUNCH(4, false, false, grid2, 256); }
+    }
 #undef KNG_LAUNCH
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev_stop[s], h->walk));
