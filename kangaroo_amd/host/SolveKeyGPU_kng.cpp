@@ -290,6 +290,19 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
     double blocked = 0, waitGpu = 0;
     bool lostWarning = false;
     const double loop0 = Timer::get_tick();
+    // KNG_STATS=1: one line when the loop ends; KNG_STATS=<seconds> (> 1): also a "(running)" line every so many seconds
+    const double statsEvery = getenv("KNG_STATS") ? atof(getenv("KNG_STATS")) : 0.0;
+    double statsNext = loop0 + statsEvery;
+    auto report = [&](const char *state) {
+      const double wall = Timer::get_tick() - loop0;
+      ::fprintf(stderr,
+                "\nSolveKeyGPU_kng GPU#%d%s: %" PRIu64 " launches in %.3f s = %.1f MK/s; points %" PRIu64 " (lost %" PRIu64 "), events %" PRIu64
+                "; GPU thread waited %.3f s for kernels, %.3f s for queue room; %d table threads busy %.3f s (%.0f ns/point), queue high water %zu of "
+                "%zu chunks\n",
+                ph->gpuId, state, launches, wall, wall > 0 ? (double)launches * (double)ph->nbKangaroo * NB_RUN / wall / 1e6 : 0.0, ingest.points, lostTotal,
+                nEvents, waitGpu, blocked, tableThreads, ingest.busy_s, ingest.points ? ingest.busy_s / (double)ingest.points * 1e9 : 0.0,
+                ingest.high_water, maxChunks);
+    };
 
     while (!endOfSearch) {
       // the launch in flight, then the next one at once: from here on the GPU is busy again while the host works
@@ -351,6 +364,11 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
         UNLOCK(ghMutex);
       }
 
+      if (statsEvery > 1.0 && Timer::get_tick() >= statsNext) {
+        report(" (running)");
+        statsNext += statsEvery;
+      }
+
       if (saveRequest && !endOfSearch) {
         ingest.flush(); // the table must hold every point the kangaroos have passed before either is written
         if (saveKangaroo) gpu->GetKangaroos(ph->px, ph->py, ph->distance);
@@ -361,16 +379,7 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
       }
     }
 
-    if (getenv("KNG_STATS")) {
-      const double wall = Timer::get_tick() - loop0;
-      ::fprintf(stderr,
-                "\nSolveKeyGPU_kng GPU#%d: %" PRIu64 " launches in %.3f s = %.1f MK/s; points %" PRIu64 " (lost %" PRIu64 "), events %" PRIu64
-                "; GPU thread waited %.3f s for kernels, %.3f s for queue room; %d table threads busy %.3f s (%.0f ns/point), queue high water %zu of "
-                "%zu chunks\n",
-                ph->gpuId, launches, wall, wall > 0 ? (double)launches * (double)ph->nbKangaroo * NB_RUN / wall / 1e6 : 0.0, ingest.points, lostTotal,
-                nEvents, waitGpu, blocked, tableThreads, ingest.busy_s, ingest.points ? ingest.busy_s / (double)ingest.points * 1e9 : 0.0,
-                ingest.high_water, maxChunks);
-    }
+    if (getenv("KNG_STATS")) report("");
   } // ~Ingest: table threads joined, whatever was still queued is dropped (the search is over)
 
   safe_delete_array(ph->px);

@@ -108,7 +108,7 @@ def test_reference_program_runs_at_the_kernel_rate_at_its_own_dp(kng, tmp_path):
     kernel = _kernel_rate_gks(kng)
     cfg = tmp_path / "in80.txt"
     cfg.write_text(IN80)
-    text = _run([exe, "-t", "0", "-gpu", "-m", "0.42", str(cfg)], 150, env={"KNG_STATS": "1"}, until="SolveKeyGPU_kng GPU#0")
+    text = _run([exe, "-t", "0", "-gpu", "-m", "0.42", str(cfg)], 150, env={"KNG_STATS": "1"}, until="SolveKeyGPU_kng GPU#0: ")
     assert "Suggested DP: 14" in text and "items lost" not in text, text[-1500:]
     m = re.search(r"SolveKeyGPU_kng GPU#0: (\d+) launches in ([0-9.]+) s = ([0-9.]+) MK/s; points (\d+) \(lost (\d+)\), events (\d+); "
                   r"GPU thread waited ([0-9.]+) s for kernels, ([0-9.]+) s for queue room", text)
