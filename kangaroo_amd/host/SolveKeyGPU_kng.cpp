@@ -31,9 +31,11 @@
 #include <vector>
 
 #include "Kangaroo.h"
+#include "SECPK1/Random.h"
 #include "Timer.h"
 #include "kangaroo_hip.h"
 #include "kng_hashtable_ext.h"
+#include "kng_host.h"
 
 #ifndef WITHGPU
 #error "SolveKeyGPU_kng.cpp replaces the GPU path: build with -DWITHGPU, like the reference's gpu=1 target"
@@ -205,17 +207,6 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
 
   const double t0 = Timer::get_tick();
 
-  if (ph->px == NULL) {
-    // no kangaroos loaded from a work file: create them, one block of GPU_GRP_SIZE per GPU thread, tame first
-    if (keyIdx == 0) ::printf("SolveKeyGPU Thread GPU#%d: creating kangaroos...\n", ph->gpuId);
-    const uint64_t nbThread = gpu->GetNbThread();
-    ph->px = new Int[ph->nbKangaroo];
-    ph->py = new Int[ph->nbKangaroo];
-    ph->distance = new Int[ph->nbKangaroo];
-    for (uint64_t i = 0; i < nbThread; i++)
-      CreateHerd(GPU_GRP_SIZE, &(ph->px[i * GPU_GRP_SIZE]), &(ph->py[i * GPU_GRP_SIZE]), &(ph->distance[i * GPU_GRP_SIZE]), TAME);
-  }
-
 #ifdef USE_SYMMETRY
   Int *wildOffset = &rangeWidthDiv4;
 #else
@@ -223,13 +214,56 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
 #endif
   gpu->SetWildOffset(wildOffset);
   gpu->SetParams(dMask, jumpDistance, jumpPointx, jumpPointy);
-  gpu->SetKangaroos(ph->px, ph->py, ph->distance);
 
-  if (workFile.length() == 0 || !saveKangaroo) {
-    // nobody will ask for the kangaroos back
-    safe_delete_array(ph->px);
-    safe_delete_array(ph->py);
-    safe_delete_array(ph->distance);
+  // Kangaroo::CreateHerd on the host takes 20 s for the 2^23 kangaroos of one MI355X (one scalar multiplication each, per GPU
+  // and per key of the input file).  When no work file hands the kangaroos in, the engine builds the herd itself
+  // (kng_build_herd: SURVEY 8 f2; same law -- distances uniform in [0, 2^rangePower), wild ones shifted by -N/2, alternating
+  // types from TAME -- from a seed drawn from the program's own generator, 6 ms of kernel time).  KNG_HOST_HERD=1 keeps the
+  // reference's host path; the symmetry build keeps it too (its equivalence-class switch is not in the device kernel).
+  bool onDevice = false;
+#ifndef USE_SYMMETRY
+  if (ph->px == NULL && !getenv("KNG_HOST_HERD")) {
+    if (kng_engine *e = kng_shim_engine(gpu)) {
+      if (keyIdx == 0) ::printf("SolveKeyGPU Thread GPU#%d: creating kangaroos...\n", ph->gpuId);
+      LOCK(ghMutex); // the generator is shared (CreateHerd takes the same lock, Kangaroo.cpp:683)
+      const uint64_t seed = ((uint64_t)rndl() << 32) ^ (uint64_t)rndl() ^ ((uint64_t)ph->gpuId << 56);
+      UNLOCK(ghMutex);
+      const uint32_t windows = (uint32_t)(rangePower + 7) / 8;
+      vector<uint64_t> table((size_t)windows * 256 * 8);
+      uint64_t bt[8], bw[8], fin[8], woff[4] = {wildOffset->bits64[0], wildOffset->bits64[1], wildOffset->bits64[2], wildOffset->bits64[3]};
+      if (rangePower >= 1 && rangePower <= 128 &&
+          kngh_herd_params(rangePower, woff, keyToSearch.x.bits64, keyToSearch.y.bits64, seed, table.data(), bt, bw, fin) == 0 &&
+          kng_build_herd(e, rangePower, seed, table.data(), windows, bt, bw, fin) == KNG_OK) {
+        onDevice = true;
+        if (workFile.length() > 0 && saveKangaroo) { // SaveWork will ask for them (GetKangaroos fills the arrays)
+          ph->px = new Int[ph->nbKangaroo];
+          ph->py = new Int[ph->nbKangaroo];
+          ph->distance = new Int[ph->nbKangaroo];
+        }
+      } else {
+        ::fprintf(stderr, "SolveKeyGPU_kng: herd creation on the device failed (%s); creating the kangaroos on the host\n", kng_last_error());
+      }
+    }
+  }
+#endif
+  if (!onDevice) {
+    if (ph->px == NULL) {
+      // no kangaroos loaded from a work file: create them, one block of GPU_GRP_SIZE per GPU thread, tame first
+      if (keyIdx == 0) ::printf("SolveKeyGPU Thread GPU#%d: creating kangaroos...\n", ph->gpuId);
+      const uint64_t nbThread = gpu->GetNbThread();
+      ph->px = new Int[ph->nbKangaroo];
+      ph->py = new Int[ph->nbKangaroo];
+      ph->distance = new Int[ph->nbKangaroo];
+      for (uint64_t i = 0; i < nbThread; i++)
+        CreateHerd(GPU_GRP_SIZE, &(ph->px[i * GPU_GRP_SIZE]), &(ph->py[i * GPU_GRP_SIZE]), &(ph->distance[i * GPU_GRP_SIZE]), TAME);
+    }
+    gpu->SetKangaroos(ph->px, ph->py, ph->distance);
+    if (workFile.length() == 0 || !saveKangaroo) {
+      // nobody will ask for the kangaroos back
+      safe_delete_array(ph->px);
+      safe_delete_array(ph->py);
+      safe_delete_array(ph->distance);
+    }
   }
 
   gpu->callKernel();
