@@ -181,9 +181,9 @@ def _power_bound(power_summary, bytes_per_jump, rate_mks):
            "e_valu_nj_per_jump": round(E_VALU_NJ_PER_WAVE_JUMP / 64.0, 2), "e_mem_nj_per_jump": round(bytes_per_jump * E_MEM_NJ_PER_BYTE, 2),
            "bytes_per_jump": bytes_per_jump, "p_cap_w": cap,
            # where each constant comes from -- none is measured in this run, each was probed once on ONE box of the pool
-           "inputs": {"p_static_w": "342 W: round 1, tools/instr_power.sh on one MI355X of the pool (profiles/r01_instr_energy.txt, s_nop on every SIMD)",
+           "inputs": {"p_static_w": "342 W: round 1, tools/archive/instr_power.sh on one MI355X of the pool (profiles/r01_instr_energy.txt, s_nop on every SIMD)",
                       "valu_nj_per_wave_instr": "MAD 1.38 / VOP3+carry 0.75 / move 0.36 nJ: same round-1 probe, same box",
-                      "mem_nj_per_byte": "0.100 nJ/B: round 2, tools/mem_power_probe.hip on another box (profiles/r02_memory_energy.txt: copy 102, read 93, write 115 pJ/B)",
+                      "mem_nj_per_byte": "0.100 nJ/B: round 2, tools/archive/mem_power_probe.hip on another box (profiles/r02_memory_energy.txt: copy 102, read 93, write 115 pJ/B)",
                       "instr_per_jump": "410 MAD + 475 slow + 140 fast VALU: static count of the loop tools/gen_walk_asm.py prints (this tree)",
                       "bytes_per_jump": "roofline.traffic / jumps when a recorded figure applies, else the design figure 208",
                       "p_cap_w": "rocm_smi power cap of the device of THIS run", "measured_power_w": "energy counter / samples of THIS run",

@@ -328,7 +328,7 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
             if (w == 0) {
                 const fe q1 = get(1), q2 = get(2), q3 = get(3);
                 const fe m1 = fe_mul(pre, q1), m2 = fe_mul(m1, q2), m3 = fe_mul(m2, q3);
-#ifdef KNG_ABL_NOINV // measurement builds only (tools/r3_sensitivity.sh): what the one inversion per CU-step costs
+#ifdef KNG_ABL_NOINV // measurement builds only (tools/archive/r3_sensitivity.sh): what the one inversion per CU-step costs
                 fe t = m3;
 #else
                 fe t = fe_inv(m3);
