@@ -108,13 +108,13 @@ def test_reference_program_runs_at_the_kernel_rate_at_its_own_dp(kng, tmp_path):
     kernel = _kernel_rate_gks(kng)
     cfg = tmp_path / "in80.txt"
     cfg.write_text(IN80)
-    text = _run([exe, "-t", "0", "-gpu", "-m", "0.42", str(cfg)], 150, env={"KNG_STATS": "1"}, until="SolveKeyGPU_kng GPU#0: ")
+    text = _run([exe, "-t", "0", "-gpu", "-m", "0.32", str(cfg)], 150, env={"KNG_STATS": "1"}, until="SolveKeyGPU_kng GPU#0: ")
     assert "Suggested DP: 14" in text and "items lost" not in text, text[-1500:]
     m = re.search(r"SolveKeyGPU_kng GPU#0: (\d+) launches in ([0-9.]+) s = ([0-9.]+) MK/s; points (\d+) \(lost (\d+)\), events (\d+); "
                   r"GPU thread waited ([0-9.]+) s for kernels, ([0-9.]+) s for queue room", text)
     assert m, text[-2500:]
     launches, wall, mks, points, lost = int(m.group(1)), float(m.group(2)), float(m.group(3)), int(m.group(4)), int(m.group(5))
-    assert launches > 1500 and lost == 0
+    assert launches > 1100 and lost == 0
     assert abs(points / launches - 32768) < 600                      # 2^29 jumps / 2^14 per launch, every one delivered
     assert mks / 1e3 >= 0.95 * kernel, (mks, kernel, text[-600:])
     st = [s for s in _status_lines(text) if s["t"] >= 8]
