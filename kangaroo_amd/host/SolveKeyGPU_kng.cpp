@@ -322,7 +322,7 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
     vector<Event> events;
     uint64_t launches = 0, lostTotal = 0, nEvents = 0;
     double blocked = 0, waitGpu = 0;
-    bool lostWarning = false;
+    bool lostWarning = false, behindWarning = false;
     const double loop0 = Timer::get_tick();
     // KNG_STATS=1: one line when the loop ends; KNG_STATS=<seconds> (> 1): also a "(running)" line every so many seconds
     const double statsEvery = getenv("KNG_STATS") ? atof(getenv("KNG_STATS")) : 0.0;
@@ -364,6 +364,14 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
       launches++;
       counters[thId] += ph->nbKangaroo * NB_RUN;
       blocked += ingest.push(recs, nb); // the view is only good until the launch after next: copy now
+      if (blocked > 1.0 && !behindWarning) {
+        // nothing is lost -- the GPU waits -- but the user should know why the rate is below the kernel's (INTEGRATION.md has
+        // the table of -d against table threads)
+        ::printf("\nWarning, the distinguished-point table cannot keep up with GPU#%d (%d table threads): the GPU waits\n"
+                 "Hint: increase dp (-d), or give the table more threads (KNG_TABLE_THREADS) if the machine has CPUs to spare\n",
+                 ph->gpuId, tableThreads);
+        behindWarning = true;
+      }
 
       // what the table threads could not simply store (Kangaroo.cpp:594-612, AddToTable :306-314)
       ingest.take_events(events);

@@ -142,3 +142,59 @@ def test_maxfound_of_the_program_is_a_floor_not_a_ceiling(tmp_path, program):
     # the status thread reads counters and table at slightly different moments, and points of the last launches are still on
     # their way: a band, but one that a table missing half of every launch (131 072 of 262 144) cannot reach
     assert 0.80 < stored / (last["count"] / 2 ** 11) < 1.05, (stored, last)
+
+
+IN56 = "0\nFFFFFFFFFFFFFF\n02E9F43F810784FF1E91D8BC7C4FF06BFEE935DA71D7350734C3472FE305FEF82A\n"   # the reference's in.txt
+IN56_ANSWER = "Priv: 0x378ABDEC51BC5D"
+
+
+def test_cpu_walkers_and_the_gpu_feed_one_table(tmp_path):
+    """`kangaroo_mi355x -t 2 -gpu`: the program's CPU threads (SolveKeyCPU, unmodified: AddToTable under ghMutex, per point) and
+    the replaced SolveKeyGPU (table threads, kng_ht_ingest, no ghMutex) insert into the same HashTable at the same time -- the
+    stripe locks of HashTable_kng.cpp are what makes that safe.  The shipped 56-bit key must come out."""
+    exe = ref_binary("kangaroo_mi355x")
+    cfg = tmp_path / "in.txt"
+    cfg.write_text(IN56)
+    out = subprocess.run([exe, "-t", "2", "-gpu", "-g", "16,128", str(cfg)], capture_output=True, text=True, timeout=300)
+    assert IN56_ANSWER in out.stdout, out.stdout[-2000:] + out.stderr[-500:]
+    assert "Number of CPU thread: 2" in out.stdout
+
+
+def test_client_mode_through_the_replaced_solvekeygpu(tmp_path):
+    """Client / server mode is outside the hot-path scope, but the replaced SolveKeyGPU still has to carry it: in
+    client mode the points go to SendToServer in the reference's lock-step shape, not to the table.  A server (the unmodified
+    CPU program, `-s`) and one GPU client (`kangaroo_mi355x -c`) on the loopback interface solve the 56-bit key."""
+    import socket
+
+    server_exe, client_exe = ref_binary("kangaroo_cpu"), ref_binary("kangaroo_mi355x")
+    cfg = tmp_path / "in.txt"
+    cfg.write_text(IN56)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    wrap = ["stdbuf", "-o0", "-e0"] if shutil.which("stdbuf") else []
+    server = subprocess.Popen(wrap + [server_exe, "-s", "-sp", str(port), "-d", "8", str(cfg)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              start_new_session=True)
+    client = None
+    try:
+        time.sleep(2.0)
+        client = subprocess.Popen(wrap + [client_exe, "-c", "127.0.0.1", "-sp", str(port), "-t", "0", "-gpu", "-g", "16,128"], stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, start_new_session=True)
+        os.set_blocking(server.stdout.fileno(), False)
+        buf, t0 = b"", time.time()
+        while time.time() - t0 < 240 and IN56_ANSWER.encode() not in buf and server.poll() is None:
+            time.sleep(0.5)
+            try:
+                chunk = server.stdout.read()
+            except BlockingIOError:
+                chunk = None
+            if chunk:
+                buf += chunk
+        text = buf.decode(errors="replace").replace("\r", "\n")
+        assert IN56_ANSWER in text, text[-2500:]
+    finally:
+        for p_ in (client, server):
+            if p_ is not None and p_.poll() is None:
+                os.killpg(p_.pid, signal.SIGKILL)
+            if p_ is not None:
+                p_.wait()
