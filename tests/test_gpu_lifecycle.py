@@ -176,3 +176,47 @@ def test_set_params_during_a_launch_takes_effect_at_the_boundary(kng, orc):
         assert sorted(map(key, got2)) == sorted(map(key, want2)), rep
         assert np.array_equal(px, ox) and np.array_equal(py, oy) and np.array_equal(pd, od), rep
     eng.close()
+
+
+def test_dp_capacity_can_be_raised_between_launches(kng, orc):
+    """kng_reserve_points (what GPUEngine::SetParams calls to make the program's `maxFound` a floor): a capacity of 1024 loses
+    points at dp 2; raised to 2^16 between launches the same herd loses none and delivers the oracle's multiset; the call is
+    refused while a launch is outstanding or undrained, and never lowers the capacity."""
+    import ctypes as C
+
+    import numpy as np
+
+    from helpers import device_distances, ints_to_array
+    from test_gpu_parity import _seeded_herd
+
+    lib = kng.load_library()
+    lib.kng_reserve_points.argtypes = [C.c_void_p, C.c_uint32]
+    grid, rp = (2, 2), 72
+    n = grid[0] * grid[1] * 128
+    x, y, true_d, woff = _seeded_herd(orc, n, rp, seed=4242)
+    jd, jx, jy, _ = orc.jump_table(rp)
+    mask = orc.dp_mask(2)
+    eng = kng.GPUEngine(grid[0], grid[1], 0, 1024)
+    eng.SetParams(mask, jd, jx, jy)
+    eng.SetWildOffset(woff)
+    eng.SetKangaroos(x, y, ints_to_array(true_d))
+    assert eng.get_option("max_found") == 1024
+    eng.callKernel()
+    assert lib.kng_reserve_points(eng._h, 1 << 16) == -4          # KNG_E_STATE: a launch is outstanding
+    eng.wait()
+    assert lib.kng_reserve_points(eng._h, 1 << 16) == -4          # ... or waited but not drained
+    got = eng.drain(raw=True)
+    assert len(got) == 1024 and eng.lastLost > 0                   # ~n*64/4 = 8192 points wanted 1024 slots
+    assert lib.kng_reserve_points(eng._h, 1 << 16) == 0 and eng.get_option("max_found") == 1 << 16
+    assert lib.kng_reserve_points(eng._h, 512) == 0 and eng.get_option("max_found") == 1 << 16    # never lowers
+    eng.maxFound = 1 << 16
+    eng._items = np.zeros(eng.maxFound, dtype=eng._items.dtype)
+    gx, gy, gd = eng.GetKangaroos(raw=True)
+    ox, oy, od = gx.copy(), gy.copy(), gd.copy()
+    eng.callKernel()
+    eng.wait()
+    got = eng.drain(raw=True)
+    want, total = orc.walk(ox, oy, od, 64, jd, jx, jy, mask, dp_cap=1 << 20)
+    key = lambda r: (int(r["kidx"]), tuple(int(v) for v in r["x"]), tuple(int(v) for v in r["d"]))  # noqa: E731
+    assert eng.lastLost == 0 and total == len(got) and sorted(map(key, got)) == sorted(map(key, want))
+    eng.close()

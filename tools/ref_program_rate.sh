@@ -11,7 +11,7 @@ OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out; mkdir -p $OUT
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp
 printf "B60E83280258A40F9CDF1649744D730D6E939DE92A2B00000000000000000000\nB60E83280258A40F9CDF1649744D730D6E939DE92A2BFFFFFFFFFFFFFFFFFFFF\n03BB113592002132E6EF387C3AEBC04667670D4CD40B2103C7D0EE4969E9FF56E4\n" > in80.txt
-for prog in kangaroo_mi355x kangaroo_hip; do
+for prog in ${PROGS:-kangaroo_mi355x kangaroo_hip}; do   # PROGS="kangaroo_hip_ht" = only class HashTable replaced
   f=$OUT/ref_program_rate_${prog}.txt
   # -m: stop by itself after SECS seconds at 25 GK/s (so that the KNG_STATS line is printed); timeout is the backstop
   M=$(python3 -c "print('%.3f' % ($SECS*25.6e9/2**${EXPECTED_LOG2:-41.11}))")   # "Expected operations: 2^41.11" at DP 14; set EXPECTED_LOG2 for other -d
