@@ -561,10 +561,11 @@ def test_solve_in_txt_with_python_host(kng):
     assert launch < 200
 
 
-@pytest.mark.parametrize("program", ["kangaroo_hip", "kangaroo_mi355x"])
+@pytest.mark.parametrize("program", ["kangaroo_hip", "kangaroo_hip_ht", "kangaroo_mi355x"])
 def test_reference_program_solves_in_txt_on_our_engine(tmp_path, program):
-    """The unmodified reference program (oracle/_ref/kangaroo_hip = reference host code + our
-    GPUEngine) solving its own shipped known-answer input on the MI355X."""
+    """The unmodified reference program (oracle/_ref/kangaroo_hip = reference host code + our GPUEngine; kangaroo_hip_ht = the
+    same with class HashTable replaced at link time; kangaroo_mi355x = with SolveKeyGPU replaced as well) solving its own
+    shipped known-answer input on the MI355X."""
     import subprocess
 
     exe = ref_binary(program)
@@ -633,7 +634,7 @@ def _run_until_saves(cmd, n_saves, max_seconds):
     return buf.decode(errors="replace")
 
 
-@pytest.mark.parametrize("program", ["kangaroo_hip", "kangaroo_mi355x"])
+@pytest.mark.parametrize("program", ["kangaroo_hip", "kangaroo_hip_ht", "kangaroo_mi355x"])
 def test_reference_workfile_roundtrip_125bit_on_our_engine(tmp_path, orc, program):
     """BASELINE.json configs[4] on one GPU: 125-bit (maximum) range, `-ws -w f -wi 3` save through
     GetKangaroos, `-winfo` / `-wcheck` of the file, `-i f` restore through SetKangaroos -- all by the
