@@ -183,7 +183,10 @@ void GPUEngine::SetParams(uint64_t dpMask, Int *distance, Int *px, Int *py) {
   const uint64_t herd = kng_nb_kangaroos(ENGINE);
   const uint64_t expected = bits >= 64 ? 0 : (herd * KNG_NB_RUN) >> bits;
   uint64_t want = 2 * expected + 4096;
-  if (want > (1ULL << 26)) want = 1ULL << 26; // what the scheduled loop can address; beyond it the mask is the caller's problem
+  // ... up to 2^22 points per launch (268 MB per pinned ring, 235 MB for this object's landing buffer): enough for every DP size
+  // from 8 up at the 2^23 herd.  A mask that asks for more (-d 7 and below at that herd: 8 M points per launch) keeps the
+  // reference's behaviour beyond that -- points above the capacity are dropped with the one-time warning.
+  if (want > (1ULL << 22)) want = 1ULL << 22;
   if (want > maxFound && !kng_outstanding(ENGINE) && !kng_undrained(ENGINE)) {
     kng_item *bigger = (kng_item *)kng_alloc_pinned((size_t)want * sizeof(kng_item));
     if (bigger && kng_reserve_points(ENGINE, (uint32_t)want) == KNG_OK) {

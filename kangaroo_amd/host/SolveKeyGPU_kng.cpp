@@ -34,6 +34,7 @@
 #include "SECPK1/Random.h"
 #include "Timer.h"
 #include "kangaroo_hip.h"
+#include "kng_cpus.h"
 #include "kng_hashtable_ext.h"
 #include "kng_host.h"
 
@@ -68,22 +69,6 @@ struct Event {
   uint32_t status;
   uint64_t stored_d[2];
 };
-
-// CPUs this process may use: affinity mask cut by the cgroup quota (the GPU boxes of this project show 256 hardware threads
-// under a quota of 16 CPUs; threads beyond the quota only take turns)
-int usable_cpus() {
-  double n = (double)thread::hardware_concurrency();
-  cpu_set_t set;
-  CPU_ZERO(&set);
-  if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < n) n = CPU_COUNT(&set);
-  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-    char q[32];
-    double period = 0;
-    if (fscanf(f, "%31s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0 && atof(q) / period < n) n = atof(q) / period;
-    fclose(f);
-  }
-  return n < 1 ? 1 : (int)(n + 0.5);
-}
 
 // the table side of one GPU thread
 class Ingest {
@@ -143,9 +128,15 @@ class Ingest {
     out.swap(events);
     events.clear();
   }
-  size_t high_water = 0;
-  uint64_t points = 0;
-  double busy_s = 0; // table-thread seconds inside kng_ht_ingest
+  struct Totals {
+    size_t high_water;
+    uint64_t points;
+    double busy_s; // table-thread seconds inside kng_ht_ingest
+  };
+  Totals totals() {
+    lock_guard<mutex> l(m);
+    return Totals{high_water, points, busy_s};
+  }
 
  private:
   void run() {
@@ -186,6 +177,9 @@ class Ingest {
   HashTable *ht;
   uint64_t off[2];
   size_t cap;
+  size_t high_water = 0;
+  uint64_t points = 0;
+  double busy_s = 0;
   mutex m;
   condition_variable work, room, idle;
   deque<Chunk *> queue;
@@ -308,7 +302,7 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
     int tableThreads = 4;
     if (const char *e = getenv("KNG_TABLE_THREADS")) tableThreads = atoi(e);
     const int gpus = nbGPUThread > 0 ? nbGPUThread : 1;
-    const int roomFor = (usable_cpus() - gpus - nbCPUThread) / gpus; // the GPU threads and the program's CPU walkers come first
+    const int roomFor = ((int)(kng_effective_cpus() + 0.5) - gpus - nbCPUThread) / gpus; // the GPU threads and the program's CPU walkers come first
     if (tableThreads > roomFor) tableThreads = roomFor;
     if (tableThreads < 1) tableThreads = 1;
     const uint64_t off[2] = {wildOffset->bits64[0], wildOffset->bits64[1]};
@@ -329,13 +323,14 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
     double statsNext = loop0 + statsEvery;
     auto report = [&](const char *state) {
       const double wall = Timer::get_tick() - loop0;
+      const Ingest::Totals tt = ingest.totals();
       ::fprintf(stderr,
                 "\nSolveKeyGPU_kng GPU#%d%s: %" PRIu64 " launches in %.3f s = %.1f MK/s; points %" PRIu64 " (lost %" PRIu64 "), events %" PRIu64
                 "; GPU thread waited %.3f s for kernels, %.3f s for queue room; %d table threads busy %.3f s (%.0f ns/point), queue high water %zu of "
                 "%zu chunks\n",
-                ph->gpuId, state, launches, wall, wall > 0 ? (double)launches * (double)ph->nbKangaroo * NB_RUN / wall / 1e6 : 0.0, ingest.points, lostTotal,
-                nEvents, waitGpu, blocked, tableThreads, ingest.busy_s, ingest.points ? ingest.busy_s / (double)ingest.points * 1e9 : 0.0,
-                ingest.high_water, maxChunks);
+                ph->gpuId, state, launches, wall, wall > 0 ? (double)launches * (double)ph->nbKangaroo * NB_RUN / wall / 1e6 : 0.0, tt.points, lostTotal,
+                nEvents, waitGpu, blocked, tableThreads, tt.busy_s, tt.points ? tt.busy_s / (double)tt.points * 1e9 : 0.0, tt.high_water,
+                maxChunks);
     };
 
     while (!endOfSearch) {

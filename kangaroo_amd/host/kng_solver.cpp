@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/kangaroo_hip.h"
+#include "kng_cpus.h"
 #include "kng_dptable.h"
 #include "kng_host.h"
 #include "kng_workfile.h"
@@ -888,33 +889,7 @@ void start_consumers(kngs_solver *s, int nc) {
 // boxes of this project show 256 hardware threads under a quota of 16 CPUs: threads beyond the quota do not run in parallel,
 // they take turns -- 32 table threads were SLOWER than 16 there, 8 s of their 27 s spent runnable but waiting for a CPU,
 // profiles/r04_dp_probe3.txt.)
-double effective_cpus() {
-    double n = (double)std::thread::hardware_concurrency();
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < n) n = CPU_COUNT(&set);
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) { // cgroup v2: "<quota|max> <period>"
-        char q[32];
-        double period = 0;
-        if (fscanf(f, "%31s %lf", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
-            const double c = atof(q) / period;
-            if (c > 0 && c < n) n = c;
-        }
-        fclose(f);
-    } else {
-        double quota = -1, period = 0;
-        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
-            if (fscanf(g, "%lf", &quota) != 1) quota = -1;
-            fclose(g);
-        }
-        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
-            if (fscanf(g, "%lf", &period) != 1) period = 0;
-            fclose(g);
-        }
-        if (quota > 0 && period > 0 && quota / period < n) n = quota / period;
-    }
-    return n < 1 ? 1 : n;
-}
+double effective_cpus() { return kng_effective_cpus(); }
 
 // A table thread inserts 11-14 M points per second of CPU time (75-90 ns each, tools/dp_table_bench); a GPU thread spends
 // 16-25 ns per point handing them over.  One GPU emits 1.5 M points/s at its own suggested DP size, eight GPUs 100 M/s at
