@@ -9,6 +9,8 @@ from the exact path, ring slot arithmetic), or a wrong but self-consistent jump 
                     instruction stream, another register allocation, the general field arithmetic; itself compared with the CPU
                     oracle in tests/test_gpu_parity.py)
   --variant dsplit  "dsplit" 1 (low-word distance streaming with L2-atomic carries) against "dsplit" 0 (full 128-bit distances)
+  --variant share   "share" 4 (256-thread blocks, one-level inversion tree: what small herds get since round 5) against "share" 8
+                    (512-thread blocks, two-level tree), at a herd both forms can walk
 
 Every launch: the two DP multisets (x, device distance, kidx of every record) must be equal.  Every --state-every launches and at
 the end: all (x, y, d) of both herds must be equal.  Nothing here uses the oracle; the reference's closest tool is the CPU/GPU
@@ -39,7 +41,7 @@ def run(args):
     rp = args.range_power
     jd, jx, jy, _ = hl.jump_table(rp)
     _, kx, ky = hl.pubkey(0x1234567 + (1 << (rp - 2)))
-    opts = {"asm": ({"asm": 1}, {"asm": 0}), "dsplit": ({"dsplit": 1}, {"dsplit": 0})}[args.variant]
+    opts = {"asm": ({"asm": 1}, {"asm": 0}), "dsplit": ({"dsplit": 1}, {"dsplit": 0}), "share": ({"share": 4}, {"share": 8})}[args.variant]
     per_launch = (gx * gy * 128 * 64) >> args.dp
     cap = max(1 << 17, 2 * per_launch + 4096)
     engines = [k.GPUEngine(gx, gy, args.device, cap, **o) for o in opts]
@@ -49,7 +51,7 @@ def run(args):
     n = engines[0].nbKangaroo
     res = {"variant": args.variant, "options": [dict(o) for o in opts], "grid": [gx, gy], "kangaroos": n, "range_power": rp, "dp": args.dp,
            "launches": 0, "jumps_per_engine": 0, "dp_records_compared": 0, "dp_differences": 0, "state_compares": 0, "state_differences": 0,
-           "exact_exits": [0, 0], "dsplit_in_effect": [e.get_option("dsplit") for e in engines], "lost": 0, "kernel_ms": [[], []]}
+           "exact_exits": [0, 0], "dsplit_in_effect": [e.get_option("dsplit") for e in engines], "share_in_effect": [e.get_option("share") for e in engines], "lost": 0, "kernel_ms": [[], []]}
     t0 = time.time()
 
     def compare_state():
@@ -99,7 +101,7 @@ def run(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variant", choices=("asm", "dsplit"), default="asm")
+    ap.add_argument("--variant", choices=("asm", "dsplit", "share"), default="asm")
     ap.add_argument("--launches", type=int, default=128)
     ap.add_argument("--grid", type=lambda s: tuple(int(v) for v in s.split(",")), default=(512, 128))
     ap.add_argument("--range-power", type=int, default=80)
