@@ -43,10 +43,10 @@ def test_low_word_distance_streaming_equals_full_distances_at_109_bits(kng):
 
 def test_one_level_inversion_tree_equals_two_level_tree(kng):
     """share 4 (256-thread blocks, new in round 5 for herds too small to fill the chip) against share 8 on the same herd of
-    2^18 kangaroos (group 2: 131 072 lanes, a size both forms walk), 1024 launches = 2^34 jumps each, DP 8: a million records
+    2^18 kangaroos (group 2: 131 072 lanes, a size both forms walk), 512 launches = 2^33 jumps each, DP 8: 33 million records
     per engine compared launch by launch, the herd nine times."""
     import diff_soak
 
-    r = diff_soak.run(_args(variant="share", launches=1024, grid=(512, 4), range_power=80, dp=8, state_every=128))
+    r = diff_soak.run(_args(variant="share", launches=512, grid=(512, 4), range_power=80, dp=8, state_every=128))
     assert r["clean"], r
-    assert r["share_in_effect"] == [4, 8] and r["dp_records_compared"] > 60_000_000 // 64
+    assert r["share_in_effect"] == [4, 8] and r["dp_records_compared"] > 30_000_000
