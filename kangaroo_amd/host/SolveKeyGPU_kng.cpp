@@ -37,6 +37,7 @@
 #include "kng_cpus.h"
 #include "kng_hashtable_ext.h"
 #include "kng_host.h"
+#include "kng_ingest.h"
 
 #ifndef WITHGPU
 #error "SolveKeyGPU_kng.cpp replaces the GPU path: build with -DWITHGPU, like the reference's gpu=1 target"
@@ -54,143 +55,7 @@ using namespace std;
   }
 #endif
 
-namespace {
-
-constexpr uint32_t CHUNK = 8192;       // points per hand-over: 512 KB, a few milliseconds of one table thread
-constexpr size_t QUEUE_LAUNCHES = 64;  // the GPU thread stalls when this many launches' points are waiting
-
-struct Chunk {
-  uint32_t n = 0;
-  kng_dp_record rec[CHUNK];
-};
-
-struct Event {
-  kng_dp_record rec;
-  uint32_t status;
-  uint64_t stored_d[2];
-};
-
-// the table side of one GPU thread
-class Ingest {
- public:
-  Ingest(HashTable *table, const uint64_t wild_off[2], int threads, size_t max_chunks) : ht(table), cap(max_chunks) {
-    off[0] = wild_off[0];
-    off[1] = wild_off[1];
-    for (int t = 0; t < threads; t++) workers.emplace_back([this] { run(); });
-  }
-  ~Ingest() {
-    {
-      lock_guard<mutex> l(m);
-      stop = true;
-    }
-    work.notify_all();
-    for (thread &t : workers) t.join();
-    for (Chunk *c : queue) delete c;
-    for (Chunk *c : spare) delete c;
-  }
-  // copy `n` records into chunks and queue them; blocks while the queue is full.  Returns the seconds spent blocked.
-  double push(const kng_dp_record *recs, uint32_t n) {
-    double blocked = 0;
-    for (uint32_t at = 0; at < n; at += CHUNK) {
-      const uint32_t k = n - at < CHUNK ? n - at : CHUNK;
-      Chunk *c = nullptr;
-      {
-        unique_lock<mutex> l(m);
-        if (queue.size() + busy >= cap) {
-          const double t0 = Timer::get_tick();
-          room.wait(l, [this] { return queue.size() + busy < cap || stop; });
-          blocked += Timer::get_tick() - t0;
-        }
-        if (!spare.empty()) {
-          c = spare.back();
-          spare.pop_back();
-        }
-      }
-      if (!c) c = new Chunk();
-      memcpy(c->rec, recs + at, (size_t)k * sizeof(kng_dp_record));
-      c->n = k;
-      {
-        lock_guard<mutex> l(m);
-        queue.push_back(c);
-        if (queue.size() + busy > high_water) high_water = queue.size() + busy;
-      }
-      work.notify_one();
-    }
-    return blocked;
-  }
-  // every queued point is in the table
-  void flush() {
-    unique_lock<mutex> l(m);
-    idle.wait(l, [this] { return queue.empty() && busy == 0; });
-  }
-  void take_events(vector<Event> &out) {
-    lock_guard<mutex> l(m);
-    out.swap(events);
-    events.clear();
-  }
-  struct Totals {
-    size_t high_water;
-    uint64_t points;
-    double busy_s; // table-thread seconds inside kng_ht_ingest
-  };
-  Totals totals() {
-    lock_guard<mutex> l(m);
-    return Totals{high_water, points, busy_s};
-  }
-
- private:
-  void run() {
-    vector<kng_ht_event> ev(CHUNK);
-    for (;;) {
-      Chunk *c;
-      {
-        unique_lock<mutex> l(m);
-        work.wait(l, [this] { return stop || !queue.empty(); });
-        if (stop) return;
-        c = queue.front();
-        queue.pop_front();
-        busy++;
-      }
-      const double t0 = Timer::get_tick();
-      uint32_t ne = 0;
-      kng_ht_ingest(ht, c->rec, c->n, off, ev.data(), CHUNK, &ne);
-      const double dt = Timer::get_tick() - t0;
-      {
-        lock_guard<mutex> l(m);
-        for (uint32_t i = 0; i < ne && i < CHUNK; i++) {
-          Event e;
-          e.rec = c->rec[ev[i].index];
-          e.status = ev[i].status;
-          e.stored_d[0] = ev[i].stored_d[0];
-          e.stored_d[1] = ev[i].stored_d[1];
-          events.push_back(e);
-        }
-        points += c->n;
-        busy_s += dt;
-        spare.push_back(c);
-        busy--;
-      }
-      room.notify_one();
-      idle.notify_all();
-    }
-  }
-  HashTable *ht;
-  uint64_t off[2];
-  size_t cap;
-  size_t high_water = 0;
-  uint64_t points = 0;
-  double busy_s = 0;
-  mutex m;
-  condition_variable work, room, idle;
-  deque<Chunk *> queue;
-  vector<Chunk *> spare;
-  vector<Event> events;
-  size_t busy = 0;
-  bool stop = false;
-  vector<thread> workers;
-};
-
-} // namespace
+using namespace kng_ingest;
 
 void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
   const int thId = ph->threadId;

@@ -69,3 +69,21 @@ def test_batch_ingest_equals_the_per_point_path(tmp_path, n, seed, buckets, thre
     assert la[0] == lb[0] and filecmp.cmp(a, b, shallow=False)
     assert "identical, table identical" in lb[1], lb
     assert lb[2].endswith("x set identical") and f"of {n}" in lb[2], lb
+
+
+@pytest.mark.parametrize("pushes,threads,cap", [(30, 3, 4), (20, 1, 2), (25, 4, 2000)])
+def test_gpu_thread_to_table_thread_queue_without_a_gpu(pushes, threads, cap):
+    """kng_ingest.h (the queue inside SolveKeyGPU_kng.cpp): two producers -- two GPU threads -- each with its own table threads
+    feed ONE table through bounded queues; entries + events must equal the records pushed, the queue must never hold more than
+    its capacity, a small capacity must hold the producer back (back-pressure instead of loss), and an Ingest destroyed with work
+    still queued must return."""
+    exe = ref_binary("ingestprobe")
+    lines = _run(exe, pushes, threads, cap)
+    assert lines[0].endswith("CONSISTENT") and "INCONSISTENT" not in lines[0], lines
+    assert lines[1] == "shutdown with queued work: returned"
+    import re
+
+    m = re.search(r"high water (\d+) / (\d+) of (\d+) blocked ([0-9.]+) s", lines[0])
+    assert int(m.group(1)) <= cap and int(m.group(2)) <= cap
+    if cap <= 4:
+        assert float(m.group(4)) > 0.0      # ~20 000 points per push against 1-3 table threads: the producer had to wait
