@@ -83,7 +83,8 @@ struct alignas(64) Stripe {
     char *ecur = nullptr, *eend = nullptr; // bump area for ENTRYs
     Spare *spare = nullptr;
     Arena *arena = nullptr;
-    uint64_t merges = 0, grows = 0, spins = 0, recycled = 0;
+    uint64_t merges = 0, grows = 0, recycled = 0; // (written under the stripe lock)
+    std::atomic<uint64_t> spins{0};                // failed attempts on the lock: counted by threads that do NOT hold it
 };
 
 struct Impl {
@@ -144,7 +145,7 @@ void release_memory(Impl *p) {
 struct StripeLock {
     Stripe &s;
     explicit StripeLock(Stripe &st) : s(st) {
-        while (s.lock.test_and_set(std::memory_order_acquire)) s.spins++;
+        while (s.lock.test_and_set(std::memory_order_acquire)) s.spins.fetch_add(1, std::memory_order_relaxed);
     }
     ~StripeLock() { s.lock.clear(std::memory_order_release); }
 };
@@ -362,6 +363,38 @@ int insert(Impl *p, HashTable *ht, uint64_t h, uint64_t x0, uint64_t x1, uint64_
     b.nbItem = ++n;
     if (n - hd->sorted > p->tail || hd->sorted == 0) fold(s, b);
     return ADD_OK;
+}
+
+// The look-ahead of kng_ht_ingest: prefetch hints computed from words read WITHOUT the stripe lock.  Racy by design -- a stale
+// or half-updated word only makes a hint useless (the addresses stay inside mappings that live until Reset) -- so the function
+// is excluded from ThreadSanitizer instead of pretending the reads are ordered; everything that decides anything happens under
+// the lock in insert().
+__attribute__((no_sanitize("thread"))) inline void hint_stages(HashTable *ht, const kng_dp_record *recs, uint32_t n, uint32_t i, uint32_t A,
+                                                               uint32_t B, uint32_t C) {
+    if (i < n) __builtin_prefetch(&ht->E[recs[i].x[2] & HASH_MASK], 0, 1);
+    if (i >= A - B && i - (A - B) < n) {
+        const kng_dp_record &r = recs[i - (A - B)];
+        ENTRY **items = __atomic_load_n(&ht->E[r.x[2] & HASH_MASK].items, __ATOMIC_RELAXED);
+        if (items) __builtin_prefetch(hdr_of(items), 0, 1);
+    }
+    if (i >= A - C && i - (A - C) < n) {
+        const kng_dp_record &r = recs[i - (A - C)];
+        const HASH_ENTRY &b = ht->E[r.x[2] & HASH_MASK];
+        ENTRY **items = __atomic_load_n(&b.items, __ATOMIC_RELAXED);
+        if (items) {
+            const Hdr *hd = hdr_of(items);
+            const uint32_t cap = __atomic_load_n(&hd->cap, __ATOMIC_RELAXED), m = __atomic_load_n(&hd->sorted, __ATOMIC_RELAXED);
+            const uint32_t nb = __atomic_load_n(&b.nbItem, __ATOMIC_RELAXED);
+            if (m <= nb && nb <= cap && nb - m <= TAIL_MAX + 8) { // stale words can say anything: bound the hint loop
+                const uint64_t *keys = keys_of(items, cap);
+                if (m) __builtin_prefetch(keys + (uint32_t)(((unsigned __int128)r.x[1] * m) >> 64), 0, 1);
+                for (uint32_t q = m; q <= nb; q += 8) { // the tail run: searched, then shifted by the insertion
+                    __builtin_prefetch(keys + q, 1, 1);
+                    __builtin_prefetch(items + q, 1, 1);
+                }
+            }
+        }
+    }
 }
 
 } // namespace
@@ -681,30 +714,7 @@ int kng_ht_ingest(HashTable *ht, const kng_dp_record *recs, uint32_t n, const ui
     // lock are hints only: a block another thread is replacing stays mapped (arenas never unmap before Reset).
     constexpr uint32_t A = 24, B = 16, C = 8;
     for (uint32_t i = 0; i < n + A; i++) {
-        if (i < n) __builtin_prefetch(&ht->E[recs[i].x[2] & HASH_MASK], 0, 1);
-        if (i >= A - B && i - (A - B) < n) {
-            const kng_dp_record &r = recs[i - (A - B)];
-            ENTRY **items = __atomic_load_n(&ht->E[r.x[2] & HASH_MASK].items, __ATOMIC_RELAXED);
-            if (items) __builtin_prefetch(hdr_of(items), 0, 1);
-        }
-        if (i >= A - C && i - (A - C) < n) {
-            const kng_dp_record &r = recs[i - (A - C)];
-            const HASH_ENTRY &b = ht->E[r.x[2] & HASH_MASK];
-            ENTRY **items = __atomic_load_n(&b.items, __ATOMIC_RELAXED);
-            if (items) {
-                const Hdr *hd = hdr_of(items);
-                const uint32_t cap = __atomic_load_n(&hd->cap, __ATOMIC_RELAXED), m = __atomic_load_n(&hd->sorted, __ATOMIC_RELAXED);
-                const uint32_t nb = __atomic_load_n(&b.nbItem, __ATOMIC_RELAXED);
-                if (m <= nb && nb <= cap && nb - m <= TAIL_MAX + 8) { // stale words can say anything: bound the hint loop
-                    const uint64_t *keys = keys_of(items, cap);
-                    if (m) __builtin_prefetch(keys + (uint32_t)(((unsigned __int128)r.x[1] * m) >> 64), 0, 1);
-                    for (uint32_t q = m; q <= nb; q += 8) { // the tail run: searched, then shifted by the insertion
-                        __builtin_prefetch(keys + q, 1, 1);
-                        __builtin_prefetch(items + q, 1, 1);
-                    }
-                }
-            }
-        }
+        hint_stages(ht, recs, n, i, A, B, C);
         if (i < A) continue;
         const uint32_t at = i - A;
         const kng_dp_record &r = recs[at];
@@ -766,7 +776,7 @@ void kng_ht_stats(HashTable *ht, kng_ht_stats_t *out) {
         for (const Stripe &s : p->stripe) {
             out->merges += s.merges;
             out->grows += s.grows;
-            out->lock_spins += s.spins;
+            out->lock_spins += s.spins.load(std::memory_order_relaxed);
             out->bytes_recycled += s.recycled;
         }
     }
