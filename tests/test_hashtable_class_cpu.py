@@ -87,3 +87,24 @@ def test_gpu_thread_to_table_thread_queue_without_a_gpu(pushes, threads, cap):
     assert int(m.group(1)) <= cap and int(m.group(2)) <= cap
     if cap <= 4:
         assert float(m.group(4)) > 0.0      # ~20 000 points per push against 1-3 table threads: the producer had to wait
+
+
+def test_link_time_replacements_are_really_linked_in():
+    """What each program binary is made of, from its symbol table: `kangaroo_hip` carries the reference's HashTable and
+    SolveKeyGPU (no kng_ht_* symbols); `kangaroo_hip_ht` our class HashTable but the reference's loop; `kangaroo_mi355x` both
+    replacements -- the batch interface, the table-thread queue (kng_ingest) and ONE definition of Kangaroo::SolveKeyGPU, the one
+    that references kng_drain_view.  A silent failure of `objcopy -W` or of the link order would show here, without a GPU."""
+    def syms(name):
+        out = subprocess.run(["nm", "-C", ref_binary(name)], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stderr
+        return out.stdout
+
+    hip, ht, full = syms("kangaroo_hip"), syms("kangaroo_hip_ht"), syms("kangaroo_mi355x")
+    assert "kng_ht_ingest" not in hip and "kng_ingest::" not in hip
+    assert " T kng_ht_ingest" in ht and "kng_ingest::" not in ht
+    assert " T kng_ht_ingest" in full and "kng_ingest::Ingest" in full and "kng_drain_view" in full
+    for text in (hip, ht, full):
+        defs = [ln for ln in text.splitlines() if "Kangaroo::SolveKeyGPU(TH_PARAM*)" in ln and ".cold" not in ln]
+        assert len(defs) == 1 and defs[0].split()[1] in ("T", "W"), defs
+    assert [ln for ln in full.splitlines() if "Kangaroo::SolveKeyGPU(TH_PARAM*)" in ln and ".cold" not in ln][0].split()[1] == "T"
+    assert "kng_drain_view" not in hip   # the reference's loop goes through GPUEngine::Launch (kng_drain)
