@@ -124,6 +124,31 @@ int kng_get_kangaroos_range(kng_engine *h, uint64_t first, uint64_t count, uint6
  * (kngh_herd_params); points are 8 limbs: x[4], y[4].  Read the herd back with kng_get_kangaroos. */
 int kng_build_herd(kng_engine *h, int range_power, uint64_t seed, const uint64_t *table, uint32_t windows,
                    const uint64_t base_tame[8], const uint64_t base_wild[8], const uint64_t final_add[8]);
+/* ---- work-file snapshot (new): the kangaroo section of a work file, Backup.cpp:525-546 (save: GPUEngine::GetKangaroos,
+ *      GPUEngine.cu:443-500, into 3 x N `Int`, then three 32-byte fwrite calls per kangaroo, every GPU thread parked
+ *      meanwhile, Kangaroo.cpp:617-626) and Backup.cpp:211-231 (restore: three 32-byte fread calls per kangaroo into
+ *      3 x N `Int`, then SetKangaroos, GPUEngine.cu:381-441).
+ * The records here ARE the file's bytes: 96 per kangaroo, {x[4], y[4], d[4]} limbs, d = the TRUE distance mod n -- for odd
+ * kIdx the 256-bit `wild_offset` (reduced mod n; NULL = none, records then carry the zero-extended device distance) has
+ * been subtracted mod n exactly as Int::ModSubK1order does (GPUEngine.cu:477).
+ * kng_snapshot packs the whole herd into a second device buffer (96 B x herd, allocated on first use and counted by
+ *   kng_memory_bytes) with one kernel on the walk stream: ordered behind a launch in flight and ahead of the next, it
+ *   freezes the state between two launches and returns at once -- the walk goes on while the records are read.
+ * kng_snapshot_read copies records first .. first+count-1 of the last snapshot to `dst` (pinned memory for speed) on the
+ *   snapshot's own stream and blocks until they have landed.  THE ONE ENTRY POINT THAT MAY BE CALLED FROM ANOTHER HOST
+ *   THREAD than the engine's own while that one launches, waits and drains; the caller only has to keep kng_snapshot /
+ *   kng_snapshot_write / kng_snapshot_release / kng_destroy away until its reads are done.
+ * kng_snapshot_write uploads records into the same buffer; kng_snapshot_restore turns records first .. first+count-1 into
+ *   herd state (adds wild_offset mod n for odd kIdx; stream-ordered like kng_set_kangaroos_range; the herd counts as loaded
+ *   once a range ending at the last kangaroo has been restored).  A distance that does not fit the 128-bit device
+ *   distance after the offset is an error (KNG_E_ARG, *bad_index = the first such kangaroo; the reference truncates,
+ *   GPUEngine.cu:410-411).
+ * kng_snapshot_release gives the buffer back. */
+int kng_snapshot(kng_engine *h, const uint64_t wild_offset[4]);
+int kng_snapshot_read(kng_engine *h, uint64_t first, uint64_t count, void *dst);
+int kng_snapshot_write(kng_engine *h, uint64_t first, uint64_t count, const void *src);
+int kng_snapshot_restore(kng_engine *h, uint64_t first, uint64_t count, const uint64_t wild_offset[4], uint64_t *bad_index);
+int kng_snapshot_release(kng_engine *h);
 /* overwrite one kangaroo; stream-ordered after an in-flight launch, never blocks the host
  * (the reference issues ten blocking 8-byte copies, GPUEngine.cu:504-530) */
 int kng_set_kangaroo(kng_engine *h, uint64_t kidx, const uint64_t x[4], const uint64_t y[4],

@@ -592,6 +592,86 @@ __global__ void __launch_bounds__(256) kng_herd_kernel(const HerdArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------
+// work-file snapshot.  The reference saves a herd by parking the GPU thread, converting the whole device state
+// into 3 x N host `Int` (GPUEngine::GetKangaroos, GPUEngine.cu:443-500: a mod-n subtraction per wild kangaroo, serial) and
+// writing it with three 32-byte fwrite calls per kangaroo (Backup.cpp:525-546) while every GPU idles.  Here one kernel packs
+// the SoA planes into the work file's own byte layout -- 96-byte records {x[4], y[4], d[4]}, d = TRUE distance mod n,
+// i.e. the wild offset already removed -- in a second device buffer (96 B x herd: 805 MB of 288 GB at the default herd), stream-
+// ordered between two launches: the walk goes on at once, and a saver thread copies the frozen records out in large
+// pieces on its own stream.  The inverse kernel turns records uploaded from a work file back into planes (-i,
+// Backup.cpp:211-231 + GPUEngine::SetKangaroos, GPUEngine.cu:381-441).
+struct SnapArgs {
+    v16 *x01, *x23, *y01, *y23;
+    uint64_t *dlo, *dhi;
+    uint64_t *rec; // 12 words per kangaroo
+    uint64_t first, count;
+    uint64_t woff[4];           // wild offset, reduced mod n; all zero = records carry device distances
+    unsigned long long *status; // unpack: [0] = records whose device distance does not fit 128 bits, [1] = first such index + 1
+};
+__device__ static const uint64_t KNG_ORDER_N[4] = {0xBFD25E8CD0364141ULL, 0xBAAEDCE6AF48A03BULL, 0xFFFFFFFFFFFFFFFEULL, 0xFFFFFFFFFFFFFFFFULL};
+
+__global__ void __launch_bounds__(256) kng_snapshot_pack_kernel(const SnapArgs a) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.count) return;
+    const uint64_t i = a.first + r;
+    const v16 x0 = a.x01[i], x1 = a.x23[i], y0 = a.y01[i], y1 = a.y23[i];
+    uint64_t d[4] = {a.dlo[i], a.dhi[i], 0, 0};
+    if (i & 1) { // wild: (dd - offset) mod n, what ModSubK1order leaves (GPUEngine.cu:477)
+        uint64_t t[4], borrow = 0;
+        for (int k = 0; k < 4; k++) {
+            const unsigned __int128 v = (unsigned __int128)d[k] - a.woff[k] - borrow;
+            t[k] = (uint64_t)v;
+            borrow = (uint64_t)(v >> 64) & 1;
+        }
+        if (borrow) {
+            uint64_t carry = 0;
+            for (int k = 0; k < 4; k++) {
+                const unsigned __int128 v = (unsigned __int128)t[k] + KNG_ORDER_N[k] + carry;
+                t[k] = (uint64_t)v;
+                carry = (uint64_t)(v >> 64);
+            }
+        }
+        for (int k = 0; k < 4; k++) d[k] = t[k];
+    }
+    v16 *o = reinterpret_cast<v16 *>(a.rec + 12 * i);
+    o[0] = x0; o[1] = x1; o[2] = y0; o[3] = y1;
+    o[4] = make_ulonglong2(d[0], d[1]);
+    o[5] = make_ulonglong2(d[2], d[3]);
+}
+
+__global__ void __launch_bounds__(256) kng_snapshot_unpack_kernel(const SnapArgs a) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.count) return;
+    const uint64_t i = a.first + r;
+    const v16 *o = reinterpret_cast<const v16 *>(a.rec + 12 * i);
+    const v16 d01 = o[4], d23 = o[5];
+    uint64_t d[4] = {d01.x, d01.y, d23.x, d23.y};
+    if (i & 1) { // wild: (d + offset) mod n (ModAddK1order, GPUEngine.cu:406-409)
+        uint64_t t[4], carry = 0;
+        for (int k = 0; k < 4; k++) {
+            const unsigned __int128 v = (unsigned __int128)d[k] + a.woff[k] + carry;
+            t[k] = (uint64_t)v;
+            carry = (uint64_t)(v >> 64);
+        }
+        uint64_t u[4], borrow = 0;
+        for (int k = 0; k < 4; k++) {
+            const unsigned __int128 v = (unsigned __int128)t[k] - KNG_ORDER_N[k] - borrow;
+            u[k] = (uint64_t)v;
+            borrow = (uint64_t)(v >> 64) & 1;
+        }
+        const bool ge = carry || !borrow; // t >= n
+        for (int k = 0; k < 4; k++) d[k] = ge ? u[k] : t[k];
+    }
+    if (d[2] | d[3]) { // the reference truncates silently (GPUEngine.cu:410-411); such a kangaroo could never be right again
+        atomicAdd(&a.status[0], 1ULL);
+        atomicMin(&a.status[1], (unsigned long long)i);
+    }
+    a.x01[i] = o[0]; a.x23[i] = o[1]; a.y01[i] = o[2]; a.y23[i] = o[3];
+    a.dlo[i] = d[0];
+    a.dhi[i] = d[1];
+}
+
+// --------------------------------------------------------------------------------------------
 // whole-run audit on the device (new; the device-side counterpart of the reference's -wcheck, Check.cpp:141-411, which
 // re-derives every stored distinguished point from its distance, and of Kangaroo::Output's final check, Kangaroo.cpp:196-206).
 // A walk error is permanent for its kangaroo: (x, y) = d*G (tame) / K + d*G (wild) holds after every exact jump and never
@@ -819,8 +899,15 @@ struct kng_engine {
     bool audit_ready = false;
     float last_audit_ms = 0.f;
     WalkAsmArgs *asm_args_host = nullptr; // pinned staging of the loop constants: uploaded stream-ordered (kng_set_params)
+    // work-file snapshot (kng_snapshot*): 96-byte records of the whole herd, its own stream (a saver thread reads while the walk runs)
+    uint64_t *snap = nullptr;
+    hipStream_t snap_stream = nullptr;
+    hipEvent_t snap_ev = nullptr;
+    unsigned long long *snap_status = nullptr, *snap_status_dev = nullptr; // pinned / device: {count, first index} of distances that do not fit
+    bool snap_taken = false;
 };
 
+static uint64_t device_bytes(const kng_engine *h); // GetMemory()
 static inline v16 *plane(const kng_engine *h, int k) { return h->planes + (size_t)k * h->n; }
 // plane 4 = distances, stored as the N low words followed by the N high words
 static inline uint64_t *dplane(const kng_engine *h, int hi) { return reinterpret_cast<uint64_t *>(plane(h, 4)) + (hi ? h->n : 0); }
@@ -1102,6 +1189,11 @@ void kng_destroy(kng_engine *h) {
     if (h->audit_res) (void)hipFree(h->audit_res);
     if (h->audit_res_host) (void)hipHostFree(h->audit_res_host);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->snap_stream) { (void)hipStreamSynchronize(h->snap_stream); (void)hipStreamDestroy(h->snap_stream); }
+    if (h->snap_ev) (void)hipEventDestroy(h->snap_ev);
+    if (h->snap) (void)hipFree(h->snap);
+    if (h->snap_status) (void)hipHostFree(h->snap_status);
+    if (h->snap_status_dev) (void)hipFree(h->snap_status_dev);
     if (h->walk) (void)hipStreamDestroy(h->walk);
     if (h->copy) (void)hipStreamDestroy(h->copy);
     delete h;
@@ -1152,7 +1244,7 @@ int kng_set_option(kng_engine *h, const char *key, int64_t value) {
         }
         free_dp_buffers(h, before != 0);
         h->view = nullptr;
-        h->bytes = 7 * (uint64_t)h->n * sizeof(v16) + JT_WORDS * 8 + 2 * 64 + (h->dp_ring ? 0 : 2 * (uint64_t)h->max_found * sizeof(DpRecord));
+        h->bytes = device_bytes(h);
         if (h->have_params) {
             int rc = upload_loop_args(h);
             if (rc != KNG_OK) return rc;
@@ -1174,17 +1266,33 @@ int kng_reserve_points(kng_engine *h, uint32_t points) {
     if (h->outstanding || h->slot_ready >= 0) return fail(KNG_E_STATE, "kng_reserve_points: a launch is outstanding or its points have not been drained");
     if (h->use_asm && points > (1u << 26)) return fail(KNG_E_ARG, "the scheduled loop addresses at most 2^26 DP records");
     HIP_TRY(hipSetDevice(h->dev));
+    // The new buffers are obtained BEFORE the old ones are given up: when the bigger allocation is refused -- a
+    // pinned ring of 2 x 268 MB against a memlock limit -- the engine keeps the buffers the device-side loop arguments point
+    // at, at their old size, and stays launchable.  (Test hook: KNG_TEST_FAIL_RESERVE=1 refuses every growth.)
     const uint32_t before = h->max_found;
-    free_dp_buffers(h, h->dp_ring != 0);
-    h->view = nullptr;
+    DpRecord *old_ring[2] = {h->ring[0], h->ring[1]}, *old_ring_dev[2] = {h->ring_dev[0], h->ring_dev[1]};
+    DpRecord *old_items[2] = {h->dp_items[0], h->dp_items[1]}, *old_h_items = h->h_items;
+    for (int s = 0; s < 2; s++) h->ring[s] = h->ring_dev[s] = h->dp_items[s] = nullptr;
+    h->h_items = nullptr;
     h->max_found = points;
-    if (int rc = alloc_dp_buffers(h)) {
-        free_dp_buffers(h, h->dp_ring != 0);
+    int rc = getenv("KNG_TEST_FAIL_RESERVE") ? fail(KNG_E_ALLOC, "pinned DP ring (%zu bytes): refused (KNG_TEST_FAIL_RESERVE)", (size_t)points * sizeof(DpRecord))
+                                             : alloc_dp_buffers(h);
+    if (rc != KNG_OK) {
+        const std::string why = kng_last_error(); // (freeing does not fail() -- but keep the text of the allocation anyway)
+        free_dp_buffers(h, h->dp_ring != 0); // whatever part of the new set was obtained
+        (void)hipGetLastError();
+        for (int s = 0; s < 2; s++) { h->ring[s] = old_ring[s]; h->ring_dev[s] = old_ring_dev[s]; h->dp_items[s] = old_items[s]; }
+        h->h_items = old_h_items;
         h->max_found = before;
-        if (alloc_dp_buffers(h) != KNG_OK) h->have_params = false; // no landing buffers at all: refuse to launch
-        return rc;
+        return fail(rc, "%s", why.c_str());
     }
-    h->bytes = 7 * (uint64_t)h->n * sizeof(v16) + JT_WORDS * 8 + 2 * 64 + (h->dp_ring ? 0 : 2 * (uint64_t)h->max_found * sizeof(DpRecord));
+    for (int s = 0; s < 2; s++) {
+        if (old_ring[s]) (void)hipHostFree(old_ring[s]);
+        if (old_items[s]) (void)hipFree(old_items[s]);
+    }
+    if (old_h_items) (void)hipHostFree(old_h_items);
+    h->view = nullptr;
+    h->bytes = device_bytes(h);
     if (h->have_params) return upload_loop_args(h);
     return KNG_OK;
 }
@@ -1317,6 +1425,117 @@ int kng_get_kangaroos_range(kng_engine *h, uint64_t first, uint64_t count, uint6
             pd[0] = sd[i]; pd[1] = sd[C + i];
         }
     }
+    return KNG_OK;
+}
+
+// ---- work-file snapshot: Backup.cpp:525-546 / :211-231 through GPUEngine::GetKangaroos / SetKangaroos ---------------------
+static uint64_t device_bytes(const kng_engine *h) {
+    return 7 * (uint64_t)h->n * sizeof(v16) + JT_WORDS * 8 + 2 * 64 + (h->dp_ring ? 0 : 2 * (uint64_t)h->max_found * sizeof(DpRecord)) +
+           (h->snap ? 96 * (uint64_t)h->n : 0);
+}
+static int snapshot_buffers(kng_engine *h) {
+    hipError_t e;
+    if (!h->snap_stream && hipStreamCreateWithFlags(&h->snap_stream, hipStreamNonBlocking) != hipSuccess) return fail(KNG_E_HIP, "stream creation failed");
+    if (!h->snap_ev && hipEventCreateWithFlags(&h->snap_ev, hipEventDisableTiming) != hipSuccess) return fail(KNG_E_HIP, "event creation failed");
+    if (!h->snap_status && (e = hipHostMalloc((void **)&h->snap_status, 64, hipHostMallocDefault)) != hipSuccess)
+        return fail(KNG_E_ALLOC, "pinned status block: %s", hipGetErrorString(e));
+    if (!h->snap_status_dev && (e = hipMalloc((void **)&h->snap_status_dev, 64)) != hipSuccess) return fail(KNG_E_ALLOC, "status block: %s", hipGetErrorString(e));
+    if (!h->snap) {
+        if ((e = hipMalloc((void **)&h->snap, 96 * (size_t)h->n)) != hipSuccess) {
+            (void)hipGetLastError();
+            h->snap = nullptr;
+            return fail(KNG_E_ALLOC, "snapshot records (%zu bytes): %s", 96 * (size_t)h->n, hipGetErrorString(e));
+        }
+        h->bytes = device_bytes(h);
+    }
+    return KNG_OK;
+}
+static void snap_args(const kng_engine *h, SnapArgs &a, uint64_t first, uint64_t count, const uint64_t wild_offset[4]) {
+    a.x01 = plane(h, 0); a.x23 = plane(h, 1); a.y01 = plane(h, 2); a.y23 = plane(h, 3);
+    a.dlo = dplane(h, 0); a.dhi = dplane(h, 1);
+    a.rec = h->snap; a.first = first; a.count = count;
+    for (int k = 0; k < 4; k++) a.woff[k] = wild_offset ? wild_offset[k] : 0;
+    a.status = nullptr;
+}
+
+int kng_snapshot(kng_engine *h, const uint64_t wild_offset[4]) {
+    if (!h) return fail(KNG_E_ARG, "null engine");
+    if (!h->have_herd) return fail(KNG_E_STATE, "no herd loaded");
+    HIP_TRY(hipSetDevice(h->dev));
+    if (int rc = snapshot_buffers(h)) return rc;
+    // a reader of the previous snapshot must be done before its records are overwritten (the caller's protocol says so;
+    // this makes a violation a delay, not a torn file)
+    HIP_TRY(hipStreamSynchronize(h->snap_stream));
+    SnapArgs a;
+    snap_args(h, a, 0, h->n, wild_offset);
+    hipLaunchKernelGGL(kng_snapshot_pack_kernel, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->walk, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->snap_ev, h->walk));
+    h->snap_taken = true;
+    return KNG_OK;
+}
+
+int kng_snapshot_read(kng_engine *h, uint64_t first, uint64_t count, void *dst) {
+    if (!h || (!dst && count)) return fail(KNG_E_ARG, "null argument");
+    if (!h->snap_taken) return fail(KNG_E_STATE, "no snapshot taken");
+    if (first > h->n || count > h->n - first) return fail(KNG_E_ARG, "range %llu+%llu outside the herd of %llu", (unsigned long long)first, (unsigned long long)count, (unsigned long long)h->n);
+    if (!count) return KNG_OK;
+    HIP_TRY(hipSetDevice(h->dev));
+    HIP_TRY(hipStreamWaitEvent(h->snap_stream, h->snap_ev, 0));
+    HIP_TRY(hipMemcpyAsync(dst, h->snap + 12 * first, 96 * (size_t)count, hipMemcpyDeviceToHost, h->snap_stream));
+    HIP_TRY(hipStreamSynchronize(h->snap_stream));
+    return KNG_OK;
+}
+
+int kng_snapshot_write(kng_engine *h, uint64_t first, uint64_t count, const void *src) {
+    if (!h || (!src && count)) return fail(KNG_E_ARG, "null argument");
+    if (first > h->n || count > h->n - first) return fail(KNG_E_ARG, "range %llu+%llu outside the herd of %llu", (unsigned long long)first, (unsigned long long)count, (unsigned long long)h->n);
+    HIP_TRY(hipSetDevice(h->dev));
+    if (int rc = snapshot_buffers(h)) return rc;
+    h->snap_taken = false; // the records are no longer those of the herd
+    if (!count) return KNG_OK;
+    HIP_TRY(hipMemcpyAsync(h->snap + 12 * first, src, 96 * (size_t)count, hipMemcpyHostToDevice, h->snap_stream));
+    HIP_TRY(hipStreamSynchronize(h->snap_stream));
+    return KNG_OK;
+}
+
+int kng_snapshot_restore(kng_engine *h, uint64_t first, uint64_t count, const uint64_t wild_offset[4], uint64_t *bad_index) {
+    if (!h) return fail(KNG_E_ARG, "null engine");
+    if (!h->snap) return fail(KNG_E_STATE, "nothing uploaded (kng_snapshot_write)");
+    if (first > h->n || count > h->n - first) return fail(KNG_E_ARG, "range %llu+%llu outside the herd of %llu", (unsigned long long)first, (unsigned long long)count, (unsigned long long)h->n);
+    HIP_TRY(hipSetDevice(h->dev));
+    if (count) {
+        SnapArgs a;
+        snap_args(h, a, first, count, wild_offset);
+        h->snap_status[0] = 0;
+        h->snap_status[1] = ~0ULL;
+        a.status = h->snap_status_dev;
+        // on the walk stream: ordered behind a launch in flight, like kng_set_kangaroos_range
+        HIP_TRY(hipMemcpyAsync(h->snap_status_dev, h->snap_status, 16, hipMemcpyHostToDevice, h->walk));
+        hipLaunchKernelGGL(kng_snapshot_unpack_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->walk, a);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h->snap_status, h->snap_status_dev, 16, hipMemcpyDeviceToHost, h->walk));
+        HIP_TRY(hipStreamSynchronize(h->walk));
+        h->products_valid = false;
+        if (h->snap_status[0]) {
+            if (bad_index) *bad_index = h->snap_status[1];
+            return fail(KNG_E_ARG, "%llu restored distances do not fit the 128-bit device distance (first: kangaroo %llu)",
+                        (unsigned long long)h->snap_status[0], (unsigned long long)h->snap_status[1]);
+        }
+    }
+    if (first + count == h->n) h->have_herd = true;
+    return KNG_OK;
+}
+
+int kng_snapshot_release(kng_engine *h) {
+    if (!h) return fail(KNG_E_ARG, "null engine");
+    HIP_TRY(hipSetDevice(h->dev));
+    if (h->snap_stream) HIP_TRY(hipStreamSynchronize(h->snap_stream));
+    HIP_TRY(hipStreamSynchronize(h->walk));
+    if (h->snap) (void)hipFree(h->snap);
+    h->snap = nullptr;
+    h->snap_taken = false;
+    h->bytes = device_bytes(h);
     return KNG_OK;
 }
 

@@ -79,10 +79,16 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.kng_audit_points.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.c_uint32]
     L.kng_drain_view.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.kng_outstanding.argtypes = [C.c_void_p]
+    L.kng_snapshot.argtypes = [C.c_void_p, C.c_void_p]
+    L.kng_snapshot_read.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.kng_snapshot_write.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.kng_snapshot_restore.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.kng_snapshot_release.argtypes = [C.c_void_p]
     for name in ("kng_device_info", "kng_default_grid", "kng_create", "kng_set_params", "kng_set_kangaroos",
                  "kng_get_kangaroos", "kng_set_kangaroos_range", "kng_get_kangaroos_range", "kng_set_kangaroo", "kng_launch", "kng_wait", "kng_drain",
                  "kng_last_kernel_ms", "kng_set_option", "kng_get_option", "kng_test_fieldop", "kng_audit_setup", "kng_audit_herd",
-                 "kng_audit_points", "kng_drain_view", "kng_outstanding"):
+                 "kng_audit_points", "kng_drain_view", "kng_outstanding", "kng_snapshot", "kng_snapshot_read", "kng_snapshot_write",
+                 "kng_snapshot_restore", "kng_snapshot_release"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -269,6 +275,38 @@ class GPUEngine:
         dd = np.zeros((count, 2), dtype=np.uint64)
         _check(self._L.kng_get_kangaroos_range(self._h, first, count, px, 4, py, 4, dd, 2))
         return px, py, dd
+
+    # -- work-file snapshot (kng_snapshot*): the kangaroo section of a work file, 96-byte records ---------------------
+    def _woff_limbs(self, with_offset: bool):
+        return _limbs(self.wildOffset % N_ORDER, 4) if (with_offset and self.wildOffset) else None
+
+    def Snapshot(self, with_offset: bool = True) -> None:
+        """Freeze the herd as work-file records {x, y, true distance mod n} in a second device buffer; returns at once
+        (stream-ordered between two launches)."""
+        w = self._woff_limbs(with_offset)
+        _check(self._L.kng_snapshot(self._h, None if w is None else w.ctypes.data))
+
+    def SnapshotRead(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        """records first .. first+count-1 of the last snapshot as a (count, 12) uint64 array: x[4] y[4] d[4]"""
+        count = self.nbKangaroo - first if count is None else count
+        out = np.zeros((count, 12), dtype=np.uint64)
+        _check(self._L.kng_snapshot_read(self._h, first, count, out.ctypes.data))
+        return out
+
+    def SnapshotWrite(self, first: int, records: np.ndarray) -> None:
+        records = np.ascontiguousarray(records, dtype=np.uint64)
+        assert records.ndim == 2 and records.shape[1] == 12
+        _check(self._L.kng_snapshot_write(self._h, first, records.shape[0], records.ctypes.data))
+
+    def SnapshotRestore(self, first: int = 0, count: int | None = None, with_offset: bool = True) -> None:
+        """records first .. first+count-1 (uploaded with SnapshotWrite) become herd state; wild distances get the offset back"""
+        count = self.nbKangaroo - first if count is None else count
+        w = self._woff_limbs(with_offset)
+        bad = C.c_uint64(0)
+        _check(self._L.kng_snapshot_restore(self._h, first, count, None if w is None else w.ctypes.data, C.byref(bad)))
+
+    def SnapshotRelease(self) -> None:
+        _check(self._L.kng_snapshot_release(self._h))
 
     def CreateHerdOnDevice(self, range_power: int, key_xy=None, seed: int = 1) -> int:
         """Build the whole herd on the GPU (kng_build_herd; replaces Kangaroo::CreateHerd + SetKangaroos).

@@ -15,17 +15,28 @@
 // host that cannot keep up stalls the GPU thread instead of losing points, and the stall is counted (KNG_STATS=1 prints it).
 //
 // Kept from the reference, because other code depends on it: the banner lines, counters[thId], hasStarted / isRunning /
-// isWaiting and the saveRequest handshake of SaveWork (Backup.cpp:454-563) -- before parking, every queued point is in the
-// table, so a work file never misses a point that the saved kangaroos have already passed -- GetKangaroos into ph->px/py/distance,
-// and client mode (SendToServer), which keeps the reference's lock-step shape: the table is not involved there.
+// isWaiting.  Client mode (SendToServer; the table is not involved there), a build with USE_SYMMETRY and an engine that could
+// not be created are not restated here: the reference's own SolveKeyGPU, still present in Kangaroo.o under a second name
+// (kng_ref_SolveKeyGPU, oracle/Makefile), runs them.
+//
+// Work files (protocol in kng_savework.h, file side in Backup_kng.cpp).  The reference parks the GPU for a whole
+// save (Kangaroo.cpp:617-626: GetKangaroos into 3 x N Int, then blocked on saveMutex until the main thread has written table
+// and kangaroos).  Here, at the launch boundary where the request is seen: kng_snapshot freezes the herd as work-file records
+// on the device, the next kernel starts at once, the points drained so far are flushed into the table, the table threads go
+// on hold until the table section is on disk, isWaiting is raised -- and the thread keeps walking; points found meanwhile wait
+// in the queue.  The file holds table and kangaroos of the same launch boundary, like the reference's.  `-i`: the thread's
+// records are uploaded as the file's bytes and unpacked on the device (kng_snapshot_write / kng_snapshot_restore).
+#include <fcntl.h>
 #include <pthread.h>
 #include <sched.h>
+#include <unistd.h>
 
 #include <condition_variable>
 #include <cinttypes>
 #include <cmath>
 #include <cstring>
 #include <deque>
+#include <unordered_map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -38,12 +49,15 @@
 #include "kng_hashtable_ext.h"
 #include "kng_host.h"
 #include "kng_ingest.h"
+#include "kng_savework.h"
 
 #ifndef WITHGPU
 #error "SolveKeyGPU_kng.cpp replaces the GPU path: build with -DWITHGPU, like the reference's gpu=1 target"
 #endif
 
 extern "C" kng_engine *kng_shim_engine(GPUEngine *g); // GPUEngine.cpp of this repo
+// the reference's own Kangaroo::SolveKeyGPU (Kangaroo.cpp:510-644), kept in Kangaroo.o under a second name (oracle/Makefile)
+extern "C" void kng_ref_SolveKeyGPU(Kangaroo *self, TH_PARAM *ph);
 
 using namespace std;
 
@@ -58,72 +72,117 @@ using namespace std;
 using namespace kng_ingest;
 
 void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
+#ifdef USE_SYMMETRY
+  kng_ref_SolveKeyGPU(this, ph); // the equivalence-class switch of that build is not in the device kernels
+#else
+  if (clientMode) { // points go to a server, not to the table: nothing here to gain (Kangaroo.cpp:577-590)
+    kng_ref_SolveKeyGPU(this, ph);
+    return;
+  }
   const int thId = ph->threadId;
 
   GPUEngine *gpu = new GPUEngine(ph->gridSizeX, ph->gridSizeY, ph->gpuId, 65536 * 2);
+  kng_engine *eng = kng_shim_engine(gpu);
 
   if (keyIdx == 0) ::printf("GPU: %s (%.1f MB used)\n", gpu->deviceName.c_str(), gpu->GetMemory() / 1048576.0);
+  if (eng == NULL) { // the constructor has said why; this thread will never find anything
+    delete gpu;
+    ph->hasStarted = true;
+    ph->isRunning = false;
+    return;
+  }
 
   const double t0 = Timer::get_tick();
 
-#ifdef USE_SYMMETRY
-  Int *wildOffset = &rangeWidthDiv4;
-#else
   Int *wildOffset = &rangeWidthDiv2;
-#endif
+  const uint64_t woff[4] = {wildOffset->bits64[0], wildOffset->bits64[1], wildOffset->bits64[2], wildOffset->bits64[3]};
   gpu->SetWildOffset(wildOffset);
   gpu->SetParams(dMask, jumpDistance, jumpPointx, jumpPointy);
 
+  // ---- the herd --------------------------------------------------------------------------------------------------------
   // Kangaroo::CreateHerd on the host takes 20 s for the 2^23 kangaroos of one MI355X (one scalar multiplication each, per GPU
-  // and per key of the input file).  When no work file hands the kangaroos in, the engine builds the herd itself
-  // (kng_build_herd: SURVEY 8 f2; same law -- distances uniform in [0, 2^rangePower), wild ones shifted by -N/2, alternating
-  // types from TAME -- from a seed drawn from the program's own generator, 6 ms of kernel time).  KNG_HOST_HERD=1 keeps the
-  // reference's host path; the symmetry build keeps it too (its equivalence-class switch is not in the device kernel).
-  bool onDevice = false;
-#ifndef USE_SYMMETRY
-  if (ph->px == NULL && !getenv("KNG_HOST_HERD")) {
-    if (kng_engine *e = kng_shim_engine(gpu)) {
-      if (keyIdx == 0) ::printf("SolveKeyGPU Thread GPU#%d: creating kangaroos...\n", ph->gpuId);
-      LOCK(ghMutex); // the generator is shared (CreateHerd takes the same lock, Kangaroo.cpp:683)
-      const uint64_t seed = ((uint64_t)rndl() << 32) ^ (uint64_t)rndl() ^ ((uint64_t)ph->gpuId << 56);
-      UNLOCK(ghMutex);
-      const uint32_t windows = (uint32_t)(rangePower + 7) / 8;
-      vector<uint64_t> table((size_t)windows * 256 * 8);
-      uint64_t bt[8], bw[8], fin[8], woff[4] = {wildOffset->bits64[0], wildOffset->bits64[1], wildOffset->bits64[2], wildOffset->bits64[3]};
-      if (rangePower >= 1 && rangePower <= 128 &&
-          kngh_herd_params(rangePower, woff, keyToSearch.x.bits64, keyToSearch.y.bits64, seed, table.data(), bt, bw, fin) == 0 &&
-          kng_build_herd(e, rangePower, seed, table.data(), windows, bt, bw, fin) == KNG_OK) {
-        onDevice = true;
-        if (workFile.length() > 0 && saveKangaroo) { // SaveWork will ask for them (GetKangaroos fills the arrays)
-          ph->px = new Int[ph->nbKangaroo];
-          ph->py = new Int[ph->nbKangaroo];
-          ph->distance = new Int[ph->nbKangaroo];
-        }
-      } else {
-        ::fprintf(stderr, "SolveKeyGPU_kng: herd creation on the device failed (%s); creating the kangaroos on the host\n", kng_last_error());
+  // and per key of the input file).  The engine builds the herd itself (kng_build_herd: SURVEY 8 f2; same law -- distances
+  // uniform in [0, 2^rangePower), wild ones shifted by -N/2, alternating types from TAME -- from a seed drawn from the
+  // program's own generator, 6 ms of kernel time).  KNG_HOST_HERD=1 keeps the reference's host path.
+  auto deviceHerd = [&]() -> bool {
+    LOCK(ghMutex); // the generator is shared (CreateHerd takes the same lock, Kangaroo.cpp:683)
+    const uint64_t seed = ((uint64_t)rndl() << 32) ^ (uint64_t)rndl() ^ ((uint64_t)ph->gpuId << 56);
+    UNLOCK(ghMutex);
+    const uint32_t windows = (uint32_t)(rangePower + 7) / 8;
+    vector<uint64_t> table((size_t)windows * 256 * 8);
+    uint64_t bt[8], bw[8], fin[8];
+    if (rangePower >= 1 && rangePower <= 128 &&
+        kngh_herd_params(rangePower, woff, keyToSearch.x.bits64, keyToSearch.y.bits64, seed, table.data(), bt, bw, fin) == 0 &&
+        kng_build_herd(eng, rangePower, seed, table.data(), windows, bt, bw, fin) == KNG_OK)
+      return true;
+    ::fprintf(stderr, "SolveKeyGPU_kng: herd creation on the device failed (%s); creating the kangaroos on the host\n", kng_last_error());
+    return false;
+  };
+  auto hostHerd = [&]() { // Kangaroo.cpp:529-541: one block of GPU_GRP_SIZE per GPU thread, tame first
+    const uint64_t nbThread = gpu->GetNbThread();
+    ph->px = new Int[ph->nbKangaroo];
+    ph->py = new Int[ph->nbKangaroo];
+    ph->distance = new Int[ph->nbKangaroo];
+    for (uint64_t i = 0; i < nbThread; i++)
+      CreateHerd(GPU_GRP_SIZE, &(ph->px[i * GPU_GRP_SIZE]), &(ph->py[i * GPU_GRP_SIZE]), &(ph->distance[i * GPU_GRP_SIZE]), TAME);
+    gpu->SetKangaroos(ph->px, ph->py, ph->distance);
+  };
+  auto createHerd = [&]() {
+    if (keyIdx == 0) ::printf("SolveKeyGPU Thread GPU#%d: creating kangaroos...\n", ph->gpuId);
+    if (getenv("KNG_HOST_HERD") || !deviceHerd()) hostHerd();
+  };
+  // The thread's share of a work file (Backup_kng.cpp left its place instead of 3 x N Int): the file's bytes go to the device
+  // in 24 MB pieces and one kernel turns them into herd state, wild offset added mod n (GPUEngine.cu:381-441 on the host).
+  auto uploadRecords = [&](const kng_save::Restore &rs) -> bool {
+    const uint64_t piece = 1u << 18;
+    uint8_t *buf = (uint8_t *)kng_alloc_pinned(piece * 96);
+    const bool pinned = buf != NULL;
+    if (!buf) buf = (uint8_t *)malloc(piece * 96);
+    const int fd = buf ? ::open(rs.file.c_str(), O_RDONLY) : -1;
+    bool ok = fd >= 0;
+    if (!ok) ::fprintf(stderr, "SolveKeyGPU_kng GPU#%d: cannot read the kangaroos of %s: %s\n", ph->gpuId, rs.file.c_str(), buf ? strerror(errno) : "out of memory");
+    for (uint64_t first = 0; ok && first < rs.count; first += piece) {
+      const uint64_t m = rs.count - first < piece ? rs.count - first : piece;
+      size_t got = 0;
+      while (got < m * 96) {
+        const ssize_t r = ::pread(fd, buf + got, m * 96 - got, (off_t)(rs.offset + first * 96 + got));
+        if (r <= 0) break;
+        got += (size_t)r;
+      }
+      if (got != m * 96) {
+        ::fprintf(stderr, "SolveKeyGPU_kng GPU#%d: %s is shorter than its header says\n", ph->gpuId, rs.file.c_str());
+        ok = false;
+      } else if (kng_snapshot_write(eng, first, m, buf) != KNG_OK) {
+        ::fprintf(stderr, "SolveKeyGPU_kng GPU#%d: %s\n", ph->gpuId, kng_last_error());
+        ok = false;
       }
     }
-  }
-#endif
-  if (!onDevice) {
-    if (ph->px == NULL) {
-      // no kangaroos loaded from a work file: create them, one block of GPU_GRP_SIZE per GPU thread, tame first
-      if (keyIdx == 0) ::printf("SolveKeyGPU Thread GPU#%d: creating kangaroos...\n", ph->gpuId);
-      const uint64_t nbThread = gpu->GetNbThread();
-      ph->px = new Int[ph->nbKangaroo];
-      ph->py = new Int[ph->nbKangaroo];
-      ph->distance = new Int[ph->nbKangaroo];
-      for (uint64_t i = 0; i < nbThread; i++)
-        CreateHerd(GPU_GRP_SIZE, &(ph->px[i * GPU_GRP_SIZE]), &(ph->py[i * GPU_GRP_SIZE]), &(ph->distance[i * GPU_GRP_SIZE]), TAME);
+    uint64_t bad = 0;
+    if (ok && kng_snapshot_restore(eng, 0, rs.count, woff, &bad) != KNG_OK) {
+      ::fprintf(stderr, "SolveKeyGPU_kng GPU#%d: %s\n", ph->gpuId, kng_last_error());
+      ok = false;
     }
+    if (fd >= 0) ::close(fd);
+    if (pinned) kng_free_pinned(buf);
+    else free(buf);
+    return ok;
+  };
+
+  if (ph->px != NULL) { // the reference's FectchKangaroos handed the kangaroos in (KNG_REF_SAVE=1)
     gpu->SetKangaroos(ph->px, ph->py, ph->distance);
-    if (workFile.length() == 0 || !saveKangaroo) {
-      // nobody will ask for the kangaroos back
-      safe_delete_array(ph->px);
-      safe_delete_array(ph->py);
-      safe_delete_array(ph->distance);
+  } else {
+    kng_save::Restore rs;
+    const bool plan = kng_save::take_restore(ph, rs);
+    if (!plan || rs.count < ph->nbKangaroo) createHerd(); // all of it, or the part the file does not have (Backup.cpp:224-229)
+    if (plan && !uploadRecords(rs)) {
+      ::fprintf(stderr, "SolveKeyGPU_kng GPU#%d: the saved kangaroos are not used\n", ph->gpuId);
+      createHerd();
     }
   }
+  // nobody asks for the kangaroos back through these arrays any more (KNG_REF_SAVE / KNG_SAVE_VERIFY allocate them when needed)
+  safe_delete_array(ph->px);
+  safe_delete_array(ph->py);
+  safe_delete_array(ph->distance);
 
   gpu->callKernel();
 
@@ -131,57 +190,38 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
 
   if (keyIdx == 0) ::printf("SolveKeyGPU Thread GPU#%d: 2^%.2f kangaroos [%.1fs]\n", ph->gpuId, log2((double)ph->nbKangaroo), (t1 - t0));
 
+  kng_save::attach(ph, eng);
+  uint64_t handled = kng_save::requested.load(); // save generations this thread has dealt with
   ph->hasStarted = true;
 
-  kng_engine *eng = kng_shim_engine(gpu);
-
-  if (clientMode || eng == NULL) {
-    // Points go to a server, not to the table: the reference's loop as it is (Kangaroo.cpp:577-590).  Also the way out when
-    // the engine could not be created: Launch() then reports the dead engine on every call, like the reference's would.
-    vector<ITEM> dps, gpuFound;
-    double lastSent = 0;
-    while (!endOfSearch) {
-      const bool ok = gpu->Launch(gpuFound);
-      if (!clientMode) {
-        if (!ok) break; // no engine: nothing will ever be found by this thread
-        continue;
-      }
-      counters[thId] += ph->nbKangaroo * NB_RUN;
-      dps.insert(dps.end(), gpuFound.begin(), gpuFound.end());
-      const double now = Timer::get_tick();
-      if (now - lastSent > SEND_PERIOD) {
-        LOCK(ghMutex);
-        SendToServer(dps, ph->threadId, ph->gpuId);
-        UNLOCK(ghMutex);
-        lastSent = now;
-      }
-      if (saveRequest && !endOfSearch) {
-        if (saveKangaroo) gpu->GetKangaroos(ph->px, ph->py, ph->distance);
-        ph->isWaiting = true;
-        LOCK(saveMutex);
-        ph->isWaiting = false;
-        UNLOCK(saveMutex);
-      }
-    }
-  } else {
+  {
     int tableThreads = 4;
     if (const char *e = getenv("KNG_TABLE_THREADS")) tableThreads = atoi(e);
     const int gpus = nbGPUThread > 0 ? nbGPUThread : 1;
     const int roomFor = ((int)(kng_effective_cpus() + 0.5) - gpus - nbCPUThread) / gpus; // the GPU threads and the program's CPU walkers come first
     if (tableThreads > roomFor) tableThreads = roomFor;
     if (tableThreads < 1) tableThreads = 1;
-    const uint64_t off[2] = {wildOffset->bits64[0], wildOffset->bits64[1]};
+    const uint64_t off[2] = {woff[0], woff[1]};
     // points per launch decide how many chunks "64 launches" are
     int bits = 0;
     for (uint64_t mk = dMask; mk; mk &= mk - 1) bits++;
     const uint64_t perLaunch = bits >= 64 ? 0 : (ph->nbKangaroo * NB_RUN) >> bits;
-    const size_t maxChunks = QUEUE_LAUNCHES * (size_t)(perLaunch / CHUNK + 1);
+    size_t maxChunks = QUEUE_LAUNCHES * (size_t)(perLaunch / CHUNK + 1);
+    if (maxChunks > QUEUE_MAX_CHUNKS) maxChunks = QUEUE_MAX_CHUNKS;
+    // while a work file's table section is being written the points wait: room for them (default 4 GiB per GPU thread)
+    size_t holdChunks = 8192;
+    if (const char *e = getenv("KNG_SAVE_QUEUE_MB")) holdChunks = (size_t)(atof(e) * 1048576.0 / sizeof(Chunk)) + 1;
     Ingest ingest(&hashTable, off, tableThreads, maxChunks);
+    if (keyIdx == 0) // what the table side can take, next to what the kernel will offer (INTEGRATION.md has the table of -d)
+      ::printf("SolveKeyGPU Thread GPU#%d: %d table thread%s (KNG_TABLE_THREADS), 2^%.1f points per launch at DP %d\n", ph->gpuId, tableThreads,
+               tableThreads == 1 ? "" : "s", perLaunch ? log2((double)perLaunch) : 0.0, bits);
 
+    const bool refSave = getenv("KNG_REF_SAVE") != NULL, verifySave = getenv("KNG_SAVE_VERIFY") != NULL;
     vector<Event> events;
-    uint64_t launches = 0, lostTotal = 0, nEvents = 0;
-    double blocked = 0, waitGpu = 0;
-    bool lostWarning = false, behindWarning = false;
+    unordered_map<uint64_t, uint64_t> resetAt; // kIdx -> last launch that still walked the kangaroo a reset replaced
+    uint64_t launches = 0, lostTotal = 0, nEvents = 0, staleEvents = 0, saves = 0;
+    double blocked = 0, waitGpu = 0, savePoint = 0;
+    bool lostWarning = false, behindWarning = false, saving = false;
     const double loop0 = Timer::get_tick();
     // KNG_STATS=1: one line when the loop ends; KNG_STATS=<seconds> (> 1): also a "(running)" line every so many seconds
     const double statsEvery = getenv("KNG_STATS") ? atof(getenv("KNG_STATS")) : 0.0;
@@ -191,11 +231,11 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
       const Ingest::Totals tt = ingest.totals();
       ::fprintf(stderr,
                 "\nSolveKeyGPU_kng GPU#%d%s: %" PRIu64 " launches in %.3f s = %.1f MK/s; points %" PRIu64 " (lost %" PRIu64 "), events %" PRIu64
-                "; GPU thread waited %.3f s for kernels, %.3f s for queue room; %d table threads busy %.3f s (%.0f ns/point), queue high water %zu of "
-                "%zu chunks\n",
+                " (+%" PRIu64 " stale); GPU thread waited %.3f s for kernels, %.3f s for queue room, %.3f s at %" PRIu64
+                " save points; %d table threads busy %.3f s (%.0f ns/point), queue high water %zu of %zu chunks\n",
                 ph->gpuId, state, launches, wall, wall > 0 ? (double)launches * (double)ph->nbKangaroo * NB_RUN / wall / 1e6 : 0.0, tt.points, lostTotal,
-                nEvents, waitGpu, blocked, tableThreads, tt.busy_s, tt.points ? tt.busy_s / (double)tt.points * 1e9 : 0.0, tt.high_water,
-                maxChunks);
+                nEvents, staleEvents, waitGpu, blocked, savePoint, saves, tableThreads, tt.busy_s, tt.points ? tt.busy_s / (double)tt.points * 1e9 : 0.0,
+                tt.high_water, maxChunks);
     };
 
     while (!endOfSearch) {
@@ -206,6 +246,26 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
         break;
       }
       waitGpu += Timer::get_tick() - tw;
+
+      // a new save request, seen at a launch boundary: freeze the herd here, before the next kernel moves it
+      const uint64_t req = kng_save::requested.load();
+      const bool savePointNow = saveRequest && !endOfSearch && req != handled && !saving;
+      const double ts = Timer::get_tick();
+      if (savePointNow && saveKangaroo) {
+        if (refSave || verifySave) { // the reference's way, for comparison: 3 x N Int through GPUEngine::GetKangaroos
+          if (ph->px == NULL) {
+            ph->px = new Int[ph->nbKangaroo];
+            ph->py = new Int[ph->nbKangaroo];
+            ph->distance = new Int[ph->nbKangaroo];
+          }
+          gpu->GetKangaroos(ph->px, ph->py, ph->distance);
+        }
+        if (!refSave) {
+          if (kng_snapshot(eng, woff) == KNG_OK) kng_save::snapshot_taken(ph, req);
+          else ::fprintf(stderr, "SolveKeyGPU_kng GPU#%d: %s\n", ph->gpuId, kng_last_error()); // SaveWork will say that this thread has nothing to save
+        }
+      }
+
       if (kng_launch(eng) != KNG_OK) {
         ::printf("GPUEngine: Kernel: %s\n", kng_last_error());
         break;
@@ -221,16 +281,31 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
         lostWarning = true;
       }
       lostTotal += lost;
-      launches++;
+      const uint64_t waited = launches++; // number of the launch these points come from; launch `waited + 1` is running
       counters[thId] += ph->nbKangaroo * NB_RUN;
-      blocked += ingest.push(recs, nb); // the view is only good until the launch after next: copy now
-      if (blocked > 1.0 && !behindWarning) {
+      blocked += ingest.push(recs, nb, waited); // the view is only good until the launch after next: copy now
+      if (blocked > 1.0 && !behindWarning && !saving) {
         // nothing is lost -- the GPU waits -- but the user should know why the rate is below the kernel's (INTEGRATION.md has
         // the table of -d against table threads)
         ::printf("\nWarning, the distinguished-point table cannot keep up with GPU#%d (%d table threads): the GPU waits\n"
                  "Hint: increase dp (-d), or give the table more threads (KNG_TABLE_THREADS) if the machine has CPUs to spare\n",
                  ph->gpuId, tableThreads);
         behindWarning = true;
+      }
+
+      if (savePointNow) {
+        // the table must hold every point the frozen kangaroos have passed, and none they have not: everything drained so far
+        // goes in, then the table threads stand still until the table section is written (they resume by themselves)
+        ingest.flush();
+        ingest.hold(req, &kng_save::finished, holdChunks);
+        handled = req;
+        saving = true;
+        saves++;
+        ph->isWaiting = true;
+        savePoint += Timer::get_tick() - ts;
+      } else if (saving && kng_save::finished.load() >= handled) {
+        ph->isWaiting = false;
+        saving = false;
       }
 
       // what the table threads could not simply store (Kangaroo.cpp:594-612, AddToTable :306-314)
@@ -240,6 +315,14 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
         for (size_t g = 0; !endOfSearch && g < events.size(); g++) {
           const Event &ev = events[g];
           const uint32_t kType = (uint32_t)(ev.rec.kidx % 2);
+          // Events arrive late (the queue), the reference's arrive before the kangaroo moves again: a kangaroo that merged
+          // into another path keeps producing that path's points until its replacement is on the device.  Points of launches
+          // that still walked the replaced kangaroo say nothing about the new one.
+          const auto was = resetAt.find(ev.rec.kidx);
+          if (was != resetAt.end() && ev.rec.reserved <= was->second) {
+            staleEvents++;
+            continue;
+          }
           bool keep = false;
           if (ev.status == ADD_COLLISION) {
             // the distance GPUEngine::Launch would have handed over (GPUEngine.cu:668-674)
@@ -258,7 +341,8 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
             // collision inside one herd (or the same point twice): that kangaroo follows another one from now on, replace it
             Int px, py, d;
             CreateHerd(1, &px, &py, &d, kType, false);
-            gpu->SetKangaroo(ev.rec.kidx, &px, &py, &d);
+            gpu->SetKangaroo(ev.rec.kidx, &px, &py, &d); // stream-ordered behind the running launch `waited + 1`
+            resetAt[ev.rec.kidx] = waited + 1;
             collisionInSameHerd++;
           }
           nEvents++;
@@ -270,17 +354,9 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
         report(" (running)");
         statsNext += statsEvery;
       }
-
-      if (saveRequest && !endOfSearch) {
-        ingest.flush(); // the table must hold every point the kangaroos have passed before either is written
-        if (saveKangaroo) gpu->GetKangaroos(ph->px, ph->py, ph->distance);
-        ph->isWaiting = true;
-        LOCK(saveMutex);
-        ph->isWaiting = false;
-        UNLOCK(saveMutex);
-      }
     }
 
+    kng_save::detach(ph); // (waits while a saver is still reading this engine's snapshot)
     if (getenv("KNG_STATS")) report("");
   } // ~Ingest: table threads joined, whatever was still queued is dropped (the search is over)
 
@@ -290,4 +366,5 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
   delete gpu;
 
   ph->isRunning = false;
+#endif
 }

@@ -110,7 +110,7 @@ def test_reference_program_runs_at_the_kernel_rate_at_its_own_dp(kng, tmp_path):
     cfg.write_text(IN80)
     text = _run([exe, "-t", "0", "-gpu", "-m", "0.32", str(cfg)], 150, env={"KNG_STATS": "1"}, until="SolveKeyGPU_kng GPU#0: ")
     assert "Suggested DP: 14" in text and "items lost" not in text, text[-1500:]
-    m = re.search(r"SolveKeyGPU_kng GPU#0: (\d+) launches in ([0-9.]+) s = ([0-9.]+) MK/s; points (\d+) \(lost (\d+)\), events (\d+); "
+    m = re.search(r"SolveKeyGPU_kng GPU#0: (\d+) launches in ([0-9.]+) s = ([0-9.]+) MK/s; points (\d+) \(lost (\d+)\), events (\d+) \(\+\d+ stale\); "
                   r"GPU thread waited ([0-9.]+) s for kernels, ([0-9.]+) s for queue room", text)
     assert m, text[-2500:]
     launches, wall, mks, points, lost = int(m.group(1)), float(m.group(2)), float(m.group(3)), int(m.group(4)), int(m.group(5))
@@ -198,3 +198,91 @@ def test_client_mode_through_the_replaced_solvekeygpu(tmp_path):
                 os.killpg(p_.pid, signal.SIGKILL)
             if p_ is not None:
                 p_.wait()
+
+
+STATS = re.compile(r"SolveKeyGPU_kng GPU#0: (\d+) launches in ([0-9.]+) s = ([0-9.]+) MK/s; points (\d+) \(lost (\d+)\), events (\d+) \(\+(\d+) stale\); "
+                   r"GPU thread waited ([0-9.]+) s for kernels, ([0-9.]+) s for queue room, ([0-9.]+) s at (\d+) save points")
+
+
+def test_work_file_saves_do_not_park_the_gpu(kng, tmp_path, orc):
+    """SURVEY 8 f3 in the reference program: `kangaroo_mi355x -t 0 -gpu -ws -w f -wi 8` at the default herd.
+    The unmodified save path parks the GPU 1.5-2.7 s per save at this herd (profiles/r06_save_cost_before.txt: GetKangaroos into
+    3 x 2^23 Int, 25 M fwrite calls).  With Backup_kng.cpp + the device snapshot the walk goes on: the run WITH saves delivers
+    >= 0.97 of the kernel rate over its whole wall time (saves included), and KNG_SAVE_VERIFY=1 compares every streamed 96-byte
+    record with GPUEngine::GetKangaroos -- the reference's own conversion, Int::ModSubK1order per wild kangaroo -- taken at the
+    same launch boundary: 0 differ.  The file is accepted by the UNMODIFIED program (-winfo, -wcheck) and its kangaroos obey
+    (x, y) = d*G / K + d*G (oracle, sampled)."""
+    exe = ref_binary("kangaroo_mi355x")
+    kernel = _kernel_rate_gks(kng)
+    cfg = tmp_path / "in80.txt"
+    cfg.write_text(IN80)
+    w = tmp_path / "save.work"
+    # -m 0.045: stops by itself after ~2^41.11 * 0.045 = 2^36.6 jumps ~ 4 s ... use the clock instead: -m large, killed after the KNG_STATS line
+    text = _run([exe, "-t", "0", "-gpu", "-d", "18", "-ws", "-w", str(w), "-wi", "8", "-m", "0.40", str(cfg)], 120,
+                env={"KNG_STATS": "1", "KNG_SAVE_VERIFY": "1"}, until="SolveKeyGPU_kng GPU#0: ")
+    m = STATS.search(text)
+    assert m, text[-3000:]
+    launches, wall, mks, lost, saves, save_s = int(m.group(1)), float(m.group(2)), float(m.group(3)), int(m.group(5)), int(m.group(11)), float(m.group(10))
+    ver = re.findall(r"SaveWork_kng verify: (\d+) streamed kangaroos, (\d+) differ", text)
+    assert saves >= 3 and len(ver) >= 3, text[-3000:]
+    assert all(int(a) == 1 << 23 and int(b) == 0 for a, b in ver), ver
+    assert lost == 0
+    # in verify mode every save point also runs the reference's GetKangaroos (about a second of host conversion with the GPU idle):
+    # take it out of the wall time -- the program prints how long its save points took
+    assert launches * (1 << 29) / (wall - save_s) / 1e9 >= 0.97 * kernel, (launches, wall, save_s, kernel)
+    # the unmodified program reads the file
+    ref = ref_binary("kangaroo_hip")
+    info = subprocess.run([ref, "-winfo", str(w)], capture_output=True, text=True, timeout=300).stdout
+    assert re.search(r"Kangaroos\s*:\s*8388608\b", info) and re.search(r"DP bits\s*:\s*18", info), info
+    chk = subprocess.run([ref, "-t", "16", "-wcheck", str(w)], capture_output=True, text=True, timeout=900).stdout
+    assert "100.000% OK" in chk, chk[-500:]
+    # the kangaroo section itself: sampled records against the oracle's scalar multiplication
+    nk = 1 << 23
+    rec = np.fromfile(w, dtype=np.uint64, offset=os.path.getsize(w) - 96 * nk).reshape(nk, 12)
+    from helpers import N_ORDER, array_to_ints
+    kx, ky = 0xBB113592002132E6EF387C3AEBC04667670D4CD40B2103C7D0EE4969E9FF56E4, None
+    start = int(IN80.split()[0], 16)
+    for i in list(range(0, 40)) + list(range(12345, nk, nk // 60)):
+        x, y, d = (array_to_ints(rec[i:i + 1, a:a + 4])[0] for a in (0, 4, 8))
+        if i % 2 == 0:  # tame: (start + d) * G   (the program searches the key shifted by -start: Kangaroo.cpp:870-905)
+            _, px, py = orc.pubkey(d % N_ORDER)
+            assert (px, py) == (x, y), i
+        else:
+            assert d < N_ORDER and (d < (1 << 80) or d > N_ORDER - (1 << 80)), (i, hex(d))  # |true distance| < 2^79 around 0 mod n
+
+
+def test_work_file_saves_without_verify_cost_nothing_and_restore_streams(kng, tmp_path):
+    """The same run without the verify hook: the rate over the WHOLE wall time, three saves inside, is >= 0.97 of the kernel
+    rate; `-i` of that file: FectchKangaroos leaves the GPU thread's records in the file, SolveKeyGPU uploads the bytes and
+    unpacks them on the device; the restored run continues the count and saves again; the unmodified program restores OUR
+    file and our program restores ITS file."""
+    exe, ref = ref_binary("kangaroo_mi355x"), ref_binary("kangaroo_hip")
+    kernel = _kernel_rate_gks(kng)
+    cfg = tmp_path / "in80.txt"
+    cfg.write_text(IN80)
+    w1, w2, w3, w4 = (tmp_path / n for n in ("a.work", "b.work", "c.work", "d.work"))
+    text = _run([exe, "-t", "0", "-gpu", "-d", "18", "-ws", "-w", str(w1), "-wi", "8", "-m", "0.33", str(cfg)], 120,
+                env={"KNG_STATS": "1"}, until="SolveKeyGPU_kng GPU#0: ")
+    m = STATS.search(text)
+    assert m, text[-3000:]
+    saves = int(m.group(11))
+    assert saves >= 3 and text.count("done [") >= 3
+    assert float(m.group(3)) / 1e3 >= 0.97 * kernel, (m.group(0), kernel)
+    sw = re.findall(r"SaveWork_kng: threads at the save point after ([0-9.]+) s, header \+ table ([0-9.]+) s \(table threads released\), (\d+) kangaroos \((\d+) streamed", text)
+    assert len(sw) >= 3 and all(int(a) == int(b) == 1 << 23 for _, _, a, b in sw), sw
+    c1 = int(re.search(r"Count\s*:\s*(\d+)", subprocess.run([ref, "-winfo", str(w1)], capture_output=True, text=True, timeout=300).stdout).group(1))
+
+    def restored(program, src, dst):
+        t = _run([program, "-t", "0", "-gpu", "-d", "18", "-i", str(src), "-ws", "-w", str(dst), "-wi", "6", str(cfg)], 40, env={"KNG_STATS": "1"}, until="done [")
+        assert "done [" in t and "2^23.00 kangaroos loaded" in t and "[0 created]" in t, t[-2000:]
+        info = subprocess.run([ref, "-winfo", str(dst)], capture_output=True, text=True, timeout=300).stdout
+        assert re.search(r"Kangaroos\s*:\s*8388608\b", info), info
+        return t, int(re.search(r"Count\s*:\s*(\d+)", info).group(1))
+
+    t2, c2 = restored(exe, w1, w2)       # ours restores ours
+    assert "creating kangaroos" not in t2 and "Fetch kangaroos" not in t2  # no FetchWalks for the GPU thread, nothing created
+    t3, c3 = restored(ref, w2, w3)       # the unmodified program restores ours
+    t4, c4 = restored(exe, w3, w4)       # ours restores the unmodified program's
+    assert c1 < c2 < c3 < c4, (c1, c2, c3, c4)
+    chk = subprocess.run([ref, "-t", "16", "-wcheck", str(w4)], capture_output=True, text=True, timeout=900).stdout
+    assert "100.000% OK" in chk, chk[-500:]
