@@ -141,24 +141,111 @@ def _kernel_name(eng) -> str:
     """Name of the walk kernel the engine launches with its current options (as rocprofv3 prints it).  `eng`: anything
     with get_option(key) -- a GPUEngine, or one GPU of a Solver."""
     share, ds, am = eng.get_option("share"), eng.get_option("dsplit"), eng.get_option("asm")
+    if am == 2:
+        return "kng_walk_valu_only_kernel"
     return f"kng_walk_share_kernel<{share}, {'true' if ds else 'false'}, {'true' if am else 'false'}>"
 
 
-def _roofline(kernel, kms, n, nb_run, group, note=None, sustained_ms=None):
+def _roofline(kernel, kms, n, nb_run, group, note=None, sustained_ms=None, step_ms=None, measured=None):
+    """`achieved` / `frac`: algorithmic bytes per launch over the time per launch.  The time is `step_ms` -- the wall-clock
+    ms_per_step of the timed region, what the driver's own clock sees -- when given, with the HIP-event
+    duration of the kernel alone beside it (`achieved_kernel`, `frac_kernel`: kernel_ms <= ms_per_step)."""
     alg = n * nb_run * ALG_BYTES_PER_JUMP
-    achieved = alg / (kms * 1e-3) / 1e9
-    traffic, tsrc = _recorded_traffic(n, group, kernel)
+    t_ms = step_ms if step_ms else kms
+    achieved = alg / (t_ms * 1e-3) / 1e9
+    if measured and measured.get("hbm_bytes_per_launch"):
+        traffic, tsrc = measured["hbm_bytes_per_launch"], measured["source"]
+    else:
+        traffic, tsrc = _recorded_traffic(n, group, kernel)
+        if measured and measured.get("error"):
+            tsrc = f"live PMC passes failed ({measured['error']}); " + (tsrc or "")
     r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+         "time_base": "ms_per_step of the timed region (wall clock, barrier to barrier)" if step_ms else "HIP-event kernel duration",
          "frac_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4), "peak_achievable": HBM_ACHIEVABLE_GBS,
+         "achieved_kernel": round(alg / (kms * 1e-3) / 1e9, 1), "frac_kernel": round(alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
          "traffic": traffic, "traffic_source": tsrc, "kernel": kernel, "kernel_ms": round(kms, 3), "alg_bytes_per_launch": alg}
     if traffic:
         r["traffic_gbs"] = round(traffic / (kms * 1e-3) / 1e9, 1)
+        r["traffic_over_algorithmic"] = round(traffic / alg, 3)
+    if measured:
+        r["traffic_passes"] = {k: v for k, v in measured.items() if k not in ("hbm_bytes_per_launch", "source")}
     if sustained_ms:
         r["frac_sustained"] = round(alg / (sustained_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         r["sustained_kernel_ms"] = round(sustained_ms, 3)
     if note:
         r["note"] = note
     return r
+
+
+def _rocprofv3():
+    import shutil
+
+    for c in (shutil.which("rocprofv3"), "/opt/rocm/bin/rocprofv3"):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+def live_traffic(kernel, n, group, grid, steps=3) -> dict:
+    """HBM bytes per launch of the walk kernel MEASURED IN THIS RUN: two rocprofv3 counter passes over a
+    child of this very script (`--pmc-child`: same engine, herd, grid, DP; 1 warm-up + `steps` launches, nothing else), one
+    per counter -- FETCH_SIZE and WRITE_SIZE do not fit one pass (MI355X_MICROARCH.md, TCC slots) -- counters only, no
+    trace domain.  Corrections as the guide prescribes: values are KiB; FETCH_SIZE reports half the bytes of wide coalesced
+    reads on gfx950, doubled.  bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, mean over the kernel's dispatches."""
+    import csv
+    import glob
+
+    exe = _rocprofv3()
+    if not exe:
+        return {"error": "rocprofv3 not found"}
+    out = {"tool": exe, "launches_per_pass": steps}
+    t0 = time.time()
+    means = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", td, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--steps", str(steps), "--warmup", "1", "--grid", f"{grid[0]},{grid[1]}"] + (["--group", str(group)] if group else [])
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            except Exception as e:  # noqa: BLE001
+                return dict(out, error=f"{counter} pass: {e}")
+            files = glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return dict(out, error=f"{counter} pass: rc {p.returncode}, {len(files)} csv; {(p.stderr or '')[-300:]}")
+            vals = []
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row.get("Counter_Name") == counter and kernel.split("<")[0] in row.get("Kernel_Name", "") and kernel.split("<")[1].rstrip(">").replace(" ", "") in row.get("Kernel_Name", "").replace(" ", ""):
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return dict(out, error=f"{counter} pass: no dispatch of {kernel} in the csv")
+            means[counter] = sum(vals) / len(vals)
+            out[counter.lower() + "_kib_mean"] = round(means[counter], 1)
+            out[counter.lower() + "_dispatches"] = len(vals)
+    b = (2.0 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024.0
+    out["seconds"] = round(time.time() - t0, 1)
+    out["hbm_bytes_per_launch"] = int(round(b))
+    out["bytes_per_jump"] = round(b / (n * 64), 1)
+    out["read_bytes_per_jump"] = round(2.0 * means["FETCH_SIZE"] * 1024.0 / (n * 64), 1)
+    out["write_bytes_per_jump"] = round(means["WRITE_SIZE"] * 1024.0 / (n * 64), 1)
+    out["source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes over `bench.py --pmc-child` "
+                     f"({steps} launches each, same engine / herd / grid), KiB -> bytes, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md")
+    return out
+
+
+def alu_ceiling(k, hl, dev, gx, gy, dp, seed, steps=8) -> dict:
+    """the integer-ALU ceiling next to the HBM roofline -- measured in this run with the headline kernel's own
+    instruction stream: engine option "asm" 2 launches kng_walk_valu_only_kernel, the scheduled loop with the global and LDS
+    accesses of its per-kangaroo loop and the flag collection left out (tools/gen_walk_asm.py VALU_ONLY; inversion tree, grid,
+    occupancy unchanged).  What the kernel would do if memory cost neither cycles nor power."""
+    r = _timed_engine(k, hl, dev, gx, gy, RANGE_POWER, None, dp, steps, 2, seed, asm=2)
+    rate = r["value"]
+    return {"value_mks": rate, "kernel_ms": r["kernel_ms"], "as_frac_of_hbm_roofline": round(rate * 1e6 * ALG_BYTES_PER_JUMP / 1e9 / HBM_PEAK_GBS, 4),
+            "kernel": "kng_walk_valu_only_kernel", "launches": steps,
+            "provenance": "measured in this run: the scheduled walk loop without its memory instructions (engine option \"asm\" 2; 1025 VALU "
+                          "instructions per kangaroo-jump of which 410 v_mad_u64_u32, same inversion tree / grid / 2 waves per SIMD); wrong results on purpose"}
 
 
 # ---- second bound: the package power cap (DESIGN.md 4.2e/4.2f).  Inputs measured on this chip in earlier rounds:
@@ -434,6 +521,9 @@ def main():
     ap.add_argument("--group", type=int, default=0, help="kangaroos per lane (0 = engine default)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 counter passes that measure roofline.traffic in this run (N=1 only)")
+    ap.add_argument("--no-alu-ceiling", action="store_true", help="skip the VALU-only leg (roofline.alu_ceiling, N=1 only)")
+    ap.add_argument("--pmc-child", action="store_true", help="internal: warm-up + K launches of the bench engine and nothing else (what the counter passes wrap)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the end-to-end host-pipeline sample (N=1 only)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary kernel-rate lines (N=1 only)")
     ap.add_argument("--host-herd", action="store_true", help="build the herd on the host and upload it (default: on the GPU)")
@@ -541,6 +631,15 @@ def main():
         eng.wait()
         eng.drain(raw=True)
 
+    if args.pmc_child:  # what the rocprofv3 counter passes of live_traffic() wrap: the same launches, nothing else, no output
+        for _ in range(args.steps):
+            eng.callKernel()
+            eng.wait()
+            eng.drain(raw=True)
+        eng.close()
+        ranks.close()
+        return
+
     kernel_ms = []
     counts = {"dps": 0, "lost": 0}
 
@@ -568,7 +667,23 @@ def main():
     jumps_per_step = n * k.KNG_NB_RUN
     value = whole_job_rate(ranks, jumps_per_step, args.steps, elapsed) / 1e6  # MK/s, whole job
     kms = float(np.mean(kernel_ms))
-    roof = _roofline(_kernel_name(eng), kms, n, k.KNG_NB_RUN, eng.get_option("group"))
+    kname, kgroup = _kernel_name(eng), eng.get_option("group")
+    cfg_now = {"group": kgroup, "lanes": eng.get_option("lanes"), "share": eng.get_option("share"), "asm_loop": eng.get_option("asm"), "mem_mb": eng.GetMemory() / 1048576.0}
+    eng.close()  # (the counter passes and the ALU-ceiling leg below bring their own engines)
+    lt = None
+    if rank == 0 and n_gpus == 1 and not args.no_pmc:
+        try:
+            lt = live_traffic(kname, n, args.group, (gx, gy))
+        except Exception as e:  # noqa: BLE001 -- the line survives a failed counter pass
+            lt = {"error": repr(e)}
+        log(f"live PMC passes: {lt}")
+    roof = _roofline(kname, kms, n, k.KNG_NB_RUN, kgroup, step_ms=elapsed / args.steps * 1e3, measured=lt)
+    if rank == 0 and n_gpus == 1 and not args.no_alu_ceiling:
+        try:
+            roof["alu_ceiling"] = alu_ceiling(k, hl, dev, gx, gy, dp, 0xA1C)
+            roof["alu_ceiling"]["kernel_rate_over_ceiling"] = round(n * k.KNG_NB_RUN / (kms * 1e-3) / 1e6 / roof["alu_ceiling"]["value_mks"], 4)
+        except Exception as e:  # noqa: BLE001
+            roof["alu_ceiling"] = {"value_mks": None, "provenance": f"failed: {e}"}
     out = {
         "metric": "kangaroo jumps/sec (MK/s)",
         "value": round(value, 2),
@@ -586,7 +701,7 @@ def main():
             "workload": f"80-bit range single key, auto DP {dp}, herd {gx}x{gy}x128 = 2^{np.log2(n):.0f} kangaroos/GPU, "
                         f"{k.KNG_NB_RUN} jumps/launch",
             "range_power": RANGE_POWER, "dp": dp, "grid": [gx, gy], "kangaroos_per_gpu": n,
-            "group": eng.get_option("group"), "lanes": eng.get_option("lanes"), "share": eng.get_option("share"), "asm_loop": eng.get_option("asm"),
+            "group": cfg_now["group"], "lanes": cfg_now["lanes"], "share": cfg_now["share"], "asm_loop": cfg_now["asm_loop"],
             "device": info["name"], "arch": info["arch"],
             "parallelism": f"independent herds x{n_gpus}, no collective" + (f"; {per_rank_note}" if per_rank_note else ""),
             "dps_per_step": round(dps / args.steps, 1), "dps_lost": lost,
@@ -600,7 +715,6 @@ def main():
     }
     bpj = (roof["traffic"] / (n * k.KNG_NB_RUN)) if roof.get("traffic") else DESIGN_BYTES_PER_JUMP
     roof["power_bound"] = _power_bound(power, round(bpj, 1), n * k.KNG_NB_RUN / (kms * 1e-3) / 1e6)
-    eng.close()
     if rank == 0 and n_gpus == 1 and not args.no_secondary:
         out["secondary"] = secondary_lines(k, hl, dev, gx, gy)
     if rank == 0 and n_gpus == 1 and not args.no_pipeline:

@@ -228,6 +228,9 @@ int kng_last_kernel_ms(const kng_engine *h, float *ms);
  *            0 = never, 1 = whenever the table allows it (all high words zero).  Reads back 0/1 = in effect.
  *   "asm"    1 (default): the per-kangaroo loop runs as one scheduled asm statement (kng_walk_asm.h); 0 = the
  *            compiler-scheduled loop (also what herds beyond 2^28 kangaroos get).  Same results.
+ *            2 = MEASUREMENT ONLY: the scheduled loop of the headline form (share 8, low-word streaming) with the global and LDS
+ *            accesses of its per-kangaroo loop left out -- the integer-ALU ceiling of the kernel (bench.py roofline.alu_ceiling,
+ *            SURVEY 8d (ii)).  WRONG results on purpose; reload the herd before walking it again.
  *   "dp_ring" 1 (default): the kernel writes its DP records straight into pinned, device-mapped host memory, one buffer
  *            per launch slot, the count landing last; 0 = device buffer + copy at drain time (rounds 1-2).  Only the
  *            buffers of the mode in use are allocated; switching releases the others and fails with KNG_E_STATE while

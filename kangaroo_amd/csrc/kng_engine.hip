@@ -265,7 +265,7 @@ KNG_DEV void walk_core(const WalkArgs &a, const uint64_t *tab, uint64_t *dlo, ui
 // data flow, same results, no hazard nops and a third of the register moves.  Its short arithmetic forms flag the lanes
 // for which they are not exact; the statement then returns BEFORE storing anything of that iteration and the wave runs
 // it through walk_core (exact on every input), then re-enters the statement behind it.
-template <int SHARE, bool DSPLIT, bool ASM>
+template <int SHARE, bool DSPLIT, bool ASM, bool NOMEM = false>
 KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
     uint64_t *const dlo = reinterpret_cast<uint64_t *>(a.d), *const dhi = dlo + a.n_kang;
     const size_t L = a.lanes;
@@ -414,7 +414,8 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
             while (true) {
                 uint32_t voff = (uint32_t)slot(k) * 16u;
                 uint32_t ks = __builtin_amdgcn_readfirstlane(k);
-                if (DSPLIT) KNG_WALK_ASM_LOOP(KNG_WALK_ASM_TEXT_DSPLIT, KNG_WALK_ASM_CLOBBERS_DSPLIT, iv, ac, ks, voff, aargs, stride, Gs, ldstab);
+                if (NOMEM) KNG_WALK_ASM_LOOP(KNG_WALK_ASM_TEXT_VALU, KNG_WALK_ASM_CLOBBERS_VALU, iv, ac, ks, voff, aargs, stride, Gs, ldstab); // measurement, option "asm" 2
+                else if (DSPLIT) KNG_WALK_ASM_LOOP(KNG_WALK_ASM_TEXT_DSPLIT, KNG_WALK_ASM_CLOBBERS_DSPLIT, iv, ac, ks, voff, aargs, stride, Gs, ldstab);
                 else KNG_WALK_ASM_LOOP(KNG_WALK_ASM_TEXT_FULL, KNG_WALK_ASM_CLOBBERS_FULL, iv, ac, ks, voff, aargs, stride, Gs, ldstab);
                 k = ks;
                 if (k >= Gs) break;
@@ -474,6 +475,19 @@ __global__ void __launch_bounds__(SHARE == 8 ? 512 : 256) __attribute__((amdgpu_
     for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
     __syncthreads();
     walk_body<SHARE, DSPLIT, ASM>(a, tab, xch);
+}
+
+// MEASUREMENT ONLY (option "asm" 2, bench.py's roofline.alu_ceiling): kng_walk_share_kernel<8, true, true> with the global and
+// LDS accesses of the per-kangaroo loop and the collection of its exactness flags left out of the scheduled statement
+// (tools/gen_walk_asm.py VALU_ONLY) -- the same 1025 VALU instructions per kangaroo-jump on whatever the registers hold, the
+// same inversion tree, the same grid: the rate the integer ALUs allow when memory costs neither cycles nor power (SURVEY 8d
+// (ii)).  Results are WRONG on purpose and the herd is not usable afterwards.
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) kng_walk_valu_only_kernel(const WalkArgs a) {
+    __shared__ uint64_t tab[JT_WORDS];
+    __shared__ v16 xch[1024];
+    for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
+    __syncthreads();
+    walk_body<8, true, true, true>(a, tab, xch);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1250,7 +1264,7 @@ int kng_set_option(kng_engine *h, const char *key, int64_t value) {
             if (rc != KNG_OK) return rc;
         }
     } else if (k == "asm") {
-        if (value < 0 || value > 1) return fail(KNG_E_ARG, "asm must be 0 or 1");
+        if (value < 0 || value > 2) return fail(KNG_E_ARG, "asm must be 0, 1 or 2 (2 = measurement only: the scheduled loop without its memory accesses)");
         if (value && (h->n > (1ull << 28) || h->max_found > (1u << 26))) return fail(KNG_E_ARG, "the scheduled loop addresses at most 2^28 kangaroos and 2^26 DP records");
         h->use_asm = (int)value;
         decide_dsplit(h); // (the automatic choice depends on which loop runs)
@@ -1694,7 +1708,10 @@ int kng_launch(kng_engine *h) {
 #define KNG_LAUNCH(SH, DS, AS, GRID, BLOCK) hipLaunchKernelGGL((kng_walk_share_kernel<SH, DS, AS>), GRID, dim3(BLOCK), 0, h->walk, a)
     // four instantiations: the scheduled loop for either distance layout, and the compiler-scheduled pair that serves herds
     // beyond 2^28 kangaroos (and is the exact path behind the scheduled loop).  Round 1-3's share = 1 family is gone.
-    if (share == 8) {
+    if (h->use_asm == 2) { // measurement: the ALU ceiling of the headline kernel (wrong results on purpose)
+        if (share != 8 || !ds) return fail(KNG_E_STATE, "\"asm\" 2 exists for the headline form only: share 8, low-word distance streaming");
+        hipLaunchKernelGGL(kng_walk_valu_only_kernel, grid2, dim3(512), 0, h->walk, a);
+    } else if (share == 8) {
         if (h->use_asm) { if (ds) KNG_LAUNCH(8, true, true, grid2, 512); else KNG_LAUNCH(8, false, true, grid2, 512); }
         else { if (ds) KNG_LAUNCH(8, true, false, grid2, 512); else KNG_LAUNCH(8, false, false, grid2, 512); }
     } else {

@@ -6,8 +6,8 @@
 // GPU host, 16 consumers inserted 30 M points/s and 96 consumers 11 M (profiles/r02_dp_ingest_*.txt).  An arena takes
 // regions of 64 KiB doubling to 256 MiB from the OS (huge pages where the system grants them), carves blocks of
 // 64, 96, 128, 192, ... bytes from them and recycles freed blocks through per-size free lists.  Nothing goes back to the OS
-// before arena_release.  Large regions on purpose: address space is free (pages arrive on first touch, the mappings are
-// MAP_NORESERVE so that they do not count against a strict overcommit policy before they are touched), but every mmap takes
+// before arena_release.  Large regions on purpose: address space is free (pages arrive on first touch; a mapping the kernel
+// refuses is asked for again with MAP_NORESERVE, then in smaller pieces), but every mmap takes
 // the process's mm lock for writing and has to wait for the page faults in flight on the neighbouring mapping it merges
 // with.  With 2 MiB regions the table threads of an 8-GPU run issued ~4000 mmaps per second and spent two thirds of their
 // time blocked behind one another (profiles/r04_dp_probe.txt: 16 consumers 138 M points/s, 32 consumers 117).
@@ -44,7 +44,8 @@ struct Arena {
     char *cur = nullptr, *end = nullptr; // bump area of the current region
     void *free_list[MAX_CLASS + 1] = {};
     std::vector<std::pair<void *, size_t>> regions; // for munmap
-    uint64_t bytes = 0;                             // taken from the OS
+    uint64_t bytes = 0;                             // taken from the OS (under the lock; readers elsewhere use the two atomics)
+    std::atomic<uint64_t> mapped{0}, touched{0};    // = bytes / bytes less the untouched tail of the current region, for status lines
 };
 
 struct Locked {
@@ -56,8 +57,13 @@ struct Locked {
     ~Locked() { a.lock.clear(std::memory_order_release); }
 };
 
+// A plain mapping first: under the default overcommit policy running out of memory then shows HERE, as a refused mmap the
+// callers turn into an error return or a message -- not later as SIGBUS / an OOM kill at first touch.  Only when
+// that is refused is the same size tried with MAP_NORESERVE (an accounting limit may refuse a 256 MiB region of which a few
+// pages will ever be touched); the callers' shrinking-region retry comes after both.
 inline void *map_region(size_t want) {
-    void *m = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    void *m = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) m = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (m == MAP_FAILED) return nullptr;
     if (want >= ((size_t)2 << 20)) (void)madvise(m, want, MADV_HUGEPAGE);
     return m;
@@ -93,9 +99,11 @@ inline void *arena_alloc(Arena &a, int c) {
         a.bytes += want;
         a.cur = static_cast<char *>(m);
         a.end = a.cur + want;
+        a.mapped.store(a.bytes, std::memory_order_relaxed);
     }
     void *p = a.cur;
     a.cur += sz;
+    a.touched.store(a.bytes - (uint64_t)(a.end - a.cur), std::memory_order_relaxed);
     return p;
 }
 
@@ -112,10 +120,14 @@ inline void arena_release(Arena &a) {
     a.cur = a.end = nullptr;
     for (void *&f : a.free_list) f = nullptr;
     a.bytes = 0;
+    a.mapped.store(0, std::memory_order_relaxed);
+    a.touched.store(0, std::memory_order_relaxed);
 }
 
-// mapped less the untouched tail of the current region
-inline uint64_t arena_touched(const Arena &a) { return a.bytes - (uint64_t)(a.end - a.cur); }
+// mapped less the untouched tail of the current region; safe to read while other threads allocate (the status
+// line's GetSizeInfo used to combine `bytes`, `cur` and `end` of three different moments)
+inline uint64_t arena_touched(const Arena &a) { return a.touched.load(std::memory_order_relaxed); }
+inline uint64_t arena_mapped(const Arena &a) { return a.mapped.load(std::memory_order_relaxed); }
 
 } // namespace kng_arena
 #endif

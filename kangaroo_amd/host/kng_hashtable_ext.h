@@ -28,9 +28,9 @@ typedef struct {
     uint64_t entries;      /* GetNbItem() */
     uint64_t bytes_mapped; /* taken from the OS by the arenas */
     uint64_t bytes_touched;
-    uint64_t merges;       /* tail runs folded into their bucket's main run */
-    uint64_t grows;        /* bucket blocks replaced by one of twice the size */
-    uint64_t bytes_recycled; /* of outgrown bucket blocks, cut into entries */
+    uint64_t merges;       /* (rounds 4-5: tail runs folded into their bucket's main run; always 0 since round 6) */
+    uint64_t grows;        /* buckets re-split into four times as many runs */
+    uint64_t bytes_recycled; /* (rounds 4-5; always 0 since round 6: freed runs go to the arena's free lists) */
     uint64_t lock_spins;   /* failed attempts on a stripe lock (contention between ingesting threads) */
 } kng_ht_stats_t;
 
@@ -44,11 +44,15 @@ extern "C" {
  * Returns 0. */
 int kng_ht_ingest(HashTable *ht, const kng_dp_record *recs, uint32_t n, const uint64_t wild_off[2], kng_ht_event *ev,
                   uint32_t ev_cap, uint32_t *n_ev);
-/* Fold every bucket's tail run into its main run: E[h].items[0 .. nbItem) ascending in x for all h, as the reference keeps
- * it after every Add.  SaveTable does this first; between Adds a bucket is "a sorted main run followed by a sorted tail of at
- * most `tail` entries" (kng_ht_set_tail, default 64; 0 = fold after every insertion: the reference's invariant at all times). */
+/* The public array of the class, on request: E[h].items[0 .. nbItem) = pointers to the bucket's entries in ascending x for all
+ * h, as the reference keeps it after every Add.  The entries live in sorted runs (kng_bucket.h), not behind a pointer array;
+ * LoadTable builds these views for the reference's only readers of items[] (Check.cpp:47,88), this call builds them at any
+ * other time, and the next insertion drops them all (items = NULL).  kng_ht_set_tail: rounds 4-5 only, does nothing. */
 void kng_ht_normalize(HashTable *ht);
 void kng_ht_set_tail(HashTable *ht, uint32_t tail);
+/* The class has no destructor (HashTable.h:66-108): a host that creates and deletes tables calls this before `delete` -- the
+ * table's memory and its slot in the registry (1024 slots) go back.  Not needed by the program, which has one table. */
+void kng_ht_release(HashTable *ht);
 void kng_ht_stats(HashTable *ht, kng_ht_stats_t *out);
 }
 #endif

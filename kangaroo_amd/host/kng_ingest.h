@@ -132,7 +132,7 @@ class Ingest {
         for (;;) {
           if (stop) return;
           if (!still_held() && !queue.empty()) break;
-          if (held) work.wait_for(l, std::chrono::milliseconds(2));
+          if (held) work.wait_until(l, std::chrono::system_clock::now() + std::chrono::milliseconds(2)); // (system clock: pthread_cond_timedwait, which ThreadSanitizer understands)
           else work.wait(l);
         }
         c = queue.front();

@@ -28,9 +28,8 @@ def _true_from_device(orc, dd, woff):
     n = dd.shape[0]
     d4 = np.zeros((n, 4), dtype=np.uint64)
     d4[:, :2] = dd
-    w4 = np.tile(ints_to_array([woff]), (n, 1))
-    sub = orc.sub_order(d4, w4)
-    d4[1::2] = sub[1::2]
+    vals = array_to_ints(d4[1::2])
+    d4[1::2] = ints_to_array([orc.sub_order(v, woff) for v in vals])
     return d4
 
 

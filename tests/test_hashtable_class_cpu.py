@@ -81,6 +81,9 @@ def test_gpu_thread_to_table_thread_queue_without_a_gpu(pushes, threads, cap):
     lines = _run(exe, pushes, threads, cap)
     assert lines[0].endswith("CONSISTENT") and "INCONSISTENT" not in lines[0], lines
     assert lines[1] == "shutdown with queued work: returned"
+    # round 6: hold for a work-file save -- table frozen, queue beyond its normal bound, producer blocked at the hold bound, the
+    # table threads release themselves when the generation is finished, events carry the tag of their push
+    assert lines[2].startswith("hold: table frozen") and lines[2].endswith(" CONSISTENT"), lines[2]
     import re
 
     m = re.search(r"high water (\d+) / (\d+) of (\d+) blocked ([0-9.]+) s", lines[0])

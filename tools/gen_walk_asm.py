@@ -44,8 +44,9 @@ NOPS = {"x": 0}
 
 
 class Loop:
-    def __init__(self, dsplit: bool):
+    def __init__(self, dsplit: bool, abl=None):
         self.dsplit = dsplit
+        self._abl_arg = abl
         A = self.A = Asm()
         # ---- operands (compiler-allocated)
         self.INV = [A.operand("v", f"%{i}") for i in range(8)]
@@ -87,7 +88,7 @@ class Loop:
         #   nostore  x, y, d not written back
         #   noglobal no global loads / stores inside the loop at all;  nolds: jump-table words taken from other registers
         #   noflags  the exactness flags are not collected (no s_or of lane masks)
-        self.abl = set(filter(None, os.environ.get("KASM_ABL", "").split(",")))
+        self.abl = set(self._abl_arg) if self._abl_arg is not None else set(filter(None, os.environ.get("KASM_ABL", "").split(",")))
         self.in_loop = False
         # cache-hint experiments (default: x, y stream with nt; products and distances plain): letters of KASM_NT flip one each
         #   S product loads nt   s product stores nt   d distance loads + stores nt   X x/y loads plain   x x/y stores plain
@@ -417,8 +418,13 @@ VPOOL = list(range(64, 256))
 SPOOL = list(range(36, 100))
 
 
-def generate(dsplit, vpool=VPOOL, spool=SPOOL):
-    lp = Loop(dsplit).build()
+# the ALU ceiling of the loop, measured live by bench.py (engine option "asm" 2): the same schedule with every global and LDS
+# access of the per-kangaroo loop and the collection of the exactness flags left out -- what remains is the VALU stream
+VALU_ONLY = ("noglobal", "nolds", "noflags")
+
+
+def generate(dsplit, vpool=VPOOL, spool=SPOOL, abl=None):
+    lp = Loop(dsplit, abl).build()
     # scheduler pressure limits (live carry masks / live temporaries beyond which only instructions that free registers issue)
     kasm.schedule(lp.A, sgpr_limit=int(os.environ.get("KASM_SLIM", "28")), vgpr_limit=int(os.environ.get("KASM_VLIM", "150")))
     used = kasm.allocate(lp.A, vpool, spool)
@@ -441,16 +447,19 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     parts = []
     info = {}
-    for dsplit in (True, False):
-        lp, used, probs = generate(dsplit)
+    for dsplit, abl in ((True, None), (False, None), (True, VALU_ONLY)):
+        lp, used, probs = generate(dsplit, abl=abl)
         if probs:
             raise SystemExit("\n".join(probs))
         text = kasm.listing(lp.A, comments=False)
         st = kasm.stats(lp.A, blocks={"A", "B", "commit", "next"})
-        info[dsplit] = (st, used)
+        if abl is None:
+            info[dsplit] = (st, used)
         clob = [f'"v{n}"' for n in sorted(used["v"])] + [f'"s{n}"' for n in sorted(used["s"])] + ['"vcc"', '"scc"', '"memory"']
-        name = "KNG_WALK_ASM_TEXT_DSPLIT" if dsplit else "KNG_WALK_ASM_TEXT_FULL"
-        parts.append(f"// distance layout: {'low word streams (DSPLIT)' if dsplit else 'both words stream'}; hot blocks: {st}\n"
+        name = "KNG_WALK_ASM_TEXT_VALU" if abl else ("KNG_WALK_ASM_TEXT_DSPLIT" if dsplit else "KNG_WALK_ASM_TEXT_FULL")
+        what = ("MEASUREMENT ONLY, WRONG RESULTS ON PURPOSE: the DSPLIT loop without its global / LDS accesses and flag collection (ALU ceiling, option \"asm\" 2)"
+                if abl else ('low word streams (DSPLIT)' if dsplit else 'both words stream'))
+        parts.append(f"// distance layout: {what}; hot blocks: {st}\n"
                      f"#define {name} \\\n" + " \\\n".join(c_string(text).split("\n")) + "\n"
                      f"#define {name.replace('TEXT', 'CLOBBERS')} {', '.join(clob)}\n")
     hdr = '''// GENERATED by tools/gen_walk_asm.py (tools/kasm.py scheduler + allocator, tools/kfield.py arithmetic) -- do not edit.
