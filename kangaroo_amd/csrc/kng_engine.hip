@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <thread>
 #include <vector>
 
@@ -266,7 +267,7 @@ KNG_DEV void walk_core(const WalkArgs &a, const uint64_t *tab, uint64_t *dlo, ui
 // for which they are not exact; the statement then returns BEFORE storing anything of that iteration and the wave runs
 // it through walk_core (exact on every input), then re-enters the statement behind it.
 template <int SHARE, bool DSPLIT, bool ASM, bool NOMEM = false>
-KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
+KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch, InvRing *ring = nullptr) {
     uint64_t *const dlo = reinterpret_cast<uint64_t *>(a.d), *const dhi = dlo + a.n_kang;
     const size_t L = a.lanes;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -372,17 +373,33 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch) {
             if (w < 2) {
                 pb = get(w + 2);
                 pre = fe_mul(acc, pb);
-                if (w) put(1, pre);
+                put(w, pre);
             }
             __syncthreads();
+            // ONE inversion, on two waves (kng_modinv.h): wave 0 leads -- division steps and f, g --, wave 1 follows one
+            // round behind with d, e and ends up holding t = 1 / (pre0 * pre1).  Round 5: wave 0 alone, waves 1-3 at the
+            // barrier: the 64 inversions of a launch of such a herd ARE the launch (1.91 ms of 1.91 ms at 65 536 kangaroos).
+#ifdef KNG_INV_ONE_WAVE // measurement builds only (tools/build_variant.sh): round 5's form, wave 0 inverts alone
             if (w == 0) {
                 const fe q1 = get(1);
-                fe t = fe_inv(fe_mul(pre, q1));
+                const fe t = fe_inv(fe_mul(pre, q1));
                 put(1, fe_mul(t, pre)); // 1/q1
                 i = fe_mul(t, q1);      // 1/pre of wave 0
             }
             __syncthreads();
             if (w == 1) i = get(1);
+#else
+            if (w == 0) {
+                fe_inv_lead(fe_mul(pre, get(1)), ring);
+            } else if (w == 1) {
+                const fe t = fe_inv_follow(ring);
+                const fe p0 = get(0);
+                put(0, fe_mul(t, pre)); // 1/pre0 (pre = this wave's own pair product)
+                i = fe_mul(t, p0);      // 1/pre1
+            }
+            __syncthreads();
+            if (w == 0) i = get(0);
+#endif
             if (w < 2) {
                 put(w + 2, fe_mul(i, acc)); // 1/pb
                 inv = fe_mul(i, pb);        // 1/acc
@@ -472,9 +489,13 @@ template <int SHARE, bool DSPLIT, bool ASM>
 __global__ void __launch_bounds__(SHARE == 8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2, 2))) kng_walk_share_kernel(const WalkArgs a) {
     __shared__ uint64_t tab[JT_WORDS];
     __shared__ v16 xch[SHARE == 8 ? 1024 : SHARE == 4 ? 512 : 1];
+    // share 4: the matrices the two waves of an inversion hand over (20 KB); the other forms get a word
+    __shared__ typename std::conditional<SHARE == 4, InvRing, uint32_t>::type ring_mem;
+    InvRing *const ring = reinterpret_cast<InvRing *>(&ring_mem);
     for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
+    if (SHARE == 4 && threadIdx.x == 0) ring->progress = 0;
     __syncthreads();
-    walk_body<SHARE, DSPLIT, ASM>(a, tab, xch);
+    walk_body<SHARE, DSPLIT, ASM>(a, tab, xch, ring);
 }
 
 // MEASUREMENT ONLY (option "asm" 2, bench.py's roofline.alu_ceiling): kng_walk_share_kernel<8, true, true> with the global and

@@ -229,4 +229,119 @@ KNG_DEV_NOINLINE fe fe_inv(const fe &a_in) {
     return r;
 }
 
+#if defined(__HIPCC__)
+// ---- one inversion, two waves (round 6; small herds: a launch of 65 536 kangaroos is 64 SERIAL inversions).
+// A lone wave issues one dependent VALU instruction every ~5 cycles, so the latency of fe_inv is its instruction count: per
+// round 360 for the 30 division steps, ~80 for (f, g) <- t (f, g), ~115 for (d, e) <- t (d, e) mod p.  Only the first two are
+// on the critical path: the division steps of round r + 1 need f, g of round r, nobody needs d, e before the end.  The LEAD
+// wave therefore runs division steps + update_fg30 and publishes each round's matrix in LDS; the FOLLOW wave -- another
+// wave of the block, on another SIMD, idle at the barrier otherwise -- applies the matrices to d, e one round behind and
+// finishes with the sign of f.  Same arithmetic, same result as fe_inv; ~20 % less latency.
+struct InvRing {
+    int32_t m[20][4][64]; // u, v, q, r of every round, per lane of the lead wave
+    int32_t sf[64];       // sign of the final f
+    uint32_t progress;    // rounds published so far; | 0x100 once the lead has left its loop.  The follow wave resets it.
+};
+
+KNG_DEV void fe_inv_lead(const fe &a_in, InvRing *ring) {
+    const fe a = fe_canon(a_in);
+    const uint32_t lane = threadIdx.x & 63;
+    int32_t f[9], g[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) f[i] = p30(i);
+    g[0] = (int32_t)(a.v[0] & M30);
+    g[1] = (int32_t)((a.v[0] >> 30) & M30);
+    g[2] = (int32_t)(((a.v[0] >> 60) | (a.v[1] << 4)) & M30);
+    g[3] = (int32_t)((a.v[1] >> 26) & M30);
+    g[4] = (int32_t)(((a.v[1] >> 56) | (a.v[2] << 8)) & M30);
+    g[5] = (int32_t)((a.v[2] >> 22) & M30);
+    g[6] = (int32_t)(((a.v[2] >> 52) | (a.v[3] << 12)) & M30);
+    g[7] = (int32_t)((a.v[3] >> 18) & M30);
+    g[8] = (int32_t)(a.v[3] >> 48);
+    int32_t zeta = -1;
+    uint32_t rounds = 0;
+#pragma unroll 1
+    for (int it = 0; it < 20; it++) {
+        int32_t u, v, q, r;
+        const uint32_t f0 = (uint32_t)f[0] | ((uint32_t)f[1] << 30);
+        const uint32_t g0 = (uint32_t)g[0] | ((uint32_t)g[1] << 30);
+        zeta = divsteps30(zeta, f0, g0, u, v, q, r);
+        ring->m[it][0][lane] = u;
+        ring->m[it][1][lane] = v;
+        ring->m[it][2][lane] = q;
+        ring->m[it][3][lane] = r;
+        rounds = (uint32_t)it + 1;
+        if (lane == 0) __hip_atomic_store(&ring->progress, rounds, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        update_fg30(f, g, u, v, q, r);
+        uint32_t nz = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) nz |= (uint32_t)g[i];
+        if (__ballot(nz != 0) == 0) break; // (wave-uniform, as in fe_inv)
+    }
+    ring->sf[lane] = f[8] >> 31;
+    if (lane == 0) __hip_atomic_store(&ring->progress, rounds | 0x100u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+KNG_DEV fe fe_inv_follow(InvRing *ring) {
+    const uint32_t lane = threadIdx.x & 63;
+    int32_t d[9], e[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        d[i] = 0;
+        e[i] = 0;
+    }
+    e[0] = 1;
+    int32_t pc0 = P30_0, pc1 = P30_1, pcm = P30_MID, pc8 = P30_8;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(pc1));
+    asm("" : "+v"(pcm));
+    asm("" : "+v"(pc8));
+#endif
+    uint32_t done = 0;
+#pragma unroll 1
+    for (;;) {
+        const uint32_t pr = __hip_atomic_load(&ring->progress, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((pr & 0xFFu) > done) {
+            const int32_t u = ring->m[done][0][lane], v = ring->m[done][1][lane], q = ring->m[done][2][lane], r = ring->m[done][3][lane];
+            update_de30(d, e, u, v, q, r, pc0, pc1, pcm, pc8);
+            done++;
+        } else if (pr & 0x100u) {
+            break;
+        } else {
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    const int32_t sf = ring->sf[lane];
+    // every lane has read what it needs: the ring is free for the next inversion (two barriers away)
+    if (lane == 0) __hip_atomic_store(&ring->progress, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // result = sign(f) * d mod p, d in (-2p, p): the tail of fe_inv
+    int32_t cond = d[8] >> 31;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        int32_t t = d[i] + (p30(i) & cond);
+        t = (t ^ sf) - sf;
+        t += c;
+        c = t >> 30;
+        d[i] = t & M30;
+    }
+    d[8] += c << 30;
+    cond = d[8] >> 31;
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        int32_t t = d[i] + (p30(i) & cond) + c;
+        c = t >> 30;
+        d[i] = t & M30;
+    }
+    d[8] += c << 30;
+    fe r;
+    r.v[0] = (uint64_t)(uint32_t)d[0] | ((uint64_t)(uint32_t)d[1] << 30) | ((uint64_t)(uint32_t)d[2] << 60);
+    r.v[1] = ((uint64_t)(uint32_t)d[2] >> 4) | ((uint64_t)(uint32_t)d[3] << 26) | ((uint64_t)(uint32_t)d[4] << 56);
+    r.v[2] = ((uint64_t)(uint32_t)d[4] >> 8) | ((uint64_t)(uint32_t)d[5] << 22) | ((uint64_t)(uint32_t)d[6] << 52);
+    r.v[3] = ((uint64_t)(uint32_t)d[6] >> 12) | ((uint64_t)(uint32_t)d[7] << 18) | ((uint64_t)(uint32_t)d[8] << 48);
+    return r;
+}
+#endif
+
 } // namespace kng

@@ -201,6 +201,9 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
     const int roomFor = ((int)(kng_effective_cpus() + 0.5) - gpus - nbCPUThread) / gpus; // the GPU threads and the program's CPU walkers come first
     if (tableThreads > roomFor) tableThreads = roomFor;
     if (tableThreads < 1) tableThreads = 1;
+    // the table threads of ALL GPU threads form one pool, each owning its share of the buckets (kng_ingest.h): every GPU thread
+    // computes the same size, whoever comes first creates it
+    const int poolThreads = tableThreads * gpus;
     const uint64_t off[2] = {woff[0], woff[1]};
     // points per launch decide how many chunks "64 launches" are
     int bits = 0;
@@ -211,10 +214,11 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
     // while a work file's table section is being written the points wait: room for them (default 4 GiB per GPU thread)
     size_t holdChunks = 8192;
     if (const char *e = getenv("KNG_SAVE_QUEUE_MB")) holdChunks = (size_t)(atof(e) * 1048576.0 / sizeof(Chunk)) + 1;
-    Ingest ingest(&hashTable, off, tableThreads, maxChunks);
+    Ingest ingest(&hashTable, off, poolThreads, maxChunks);
     if (keyIdx == 0) // what the table side can take, next to what the kernel will offer (INTEGRATION.md has the table of -d)
-      ::printf("SolveKeyGPU Thread GPU#%d: %d table thread%s (KNG_TABLE_THREADS), 2^%.1f points per launch at DP %d\n", ph->gpuId, tableThreads,
-               tableThreads == 1 ? "" : "s", perLaunch ? log2((double)perLaunch) : 0.0, bits);
+      ::printf("SolveKeyGPU Thread GPU#%d: 2^%.1f points per launch at DP %d into a pool of %d table thread%s (%d per GPU thread, "
+               "KNG_TABLE_THREADS; one thread takes ~10 M points/s)\n",
+               ph->gpuId, perLaunch ? log2((double)perLaunch) : 0.0, bits, ingest.threads(), ingest.threads() == 1 ? "" : "s", tableThreads);
 
     const bool refSave = getenv("KNG_REF_SAVE") != NULL, verifySave = getenv("KNG_SAVE_VERIFY") != NULL;
     vector<Event> events;
@@ -232,9 +236,9 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
       ::fprintf(stderr,
                 "\nSolveKeyGPU_kng GPU#%d%s: %" PRIu64 " launches in %.3f s = %.1f MK/s; points %" PRIu64 " (lost %" PRIu64 "), events %" PRIu64
                 " (+%" PRIu64 " stale); GPU thread waited %.3f s for kernels, %.3f s for queue room, %.3f s at %" PRIu64
-                " save points; %d table threads busy %.3f s (%.0f ns/point), queue high water %zu of %zu chunks\n",
+                " save points; pool of %d table threads busy %.3f s with this GPU's points (%.0f ns/point), queue high water %zu of %zu chunks\n",
                 ph->gpuId, state, launches, wall, wall > 0 ? (double)launches * (double)ph->nbKangaroo * NB_RUN / wall / 1e6 : 0.0, tt.points, lostTotal,
-                nEvents, staleEvents, waitGpu, blocked, savePoint, saves, tableThreads, tt.busy_s, tt.points ? tt.busy_s / (double)tt.points * 1e9 : 0.0,
+                nEvents, staleEvents, waitGpu, blocked, savePoint, saves, ingest.threads(), tt.busy_s, tt.points ? tt.busy_s / (double)tt.points * 1e9 : 0.0,
                 tt.high_water, maxChunks);
     };
 
@@ -289,7 +293,7 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
         // the table of -d against table threads)
         ::printf("\nWarning, the distinguished-point table cannot keep up with GPU#%d (%d table threads): the GPU waits\n"
                  "Hint: increase dp (-d), or give the table more threads (KNG_TABLE_THREADS) if the machine has CPUs to spare\n",
-                 ph->gpuId, tableThreads);
+                 ph->gpuId, ingest.threads());
         behindWarning = true;
       }
 

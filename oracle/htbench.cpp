@@ -6,6 +6,7 @@
  *
  *   htbench add    <points> <report-every>            one thread, HashTable::Add(Int*, Int*, type) per point
  *   htbench ingest <points> <report-every> <threads>  kng_ht_ingest, 32768-point batches, <threads> threads at once
+ *   htbench ingestp <points> <report-every> <threads> the same, every thread feeding its own 1/<threads> of the buckets
  * prints: entries, ns per point (per thread) over the last interval, points/s of all threads, resident MB.
  */
 #include <pthread.h>
@@ -68,6 +69,7 @@ static std::atomic<uint64_t> done_points;
 struct job {
   uint64_t points;
   uint64_t seed;
+  uint32_t lo, hi; /* buckets this thread feeds: all of them (ingest), or its own range (ingestp: what owner-partitioned table threads see) */
 };
 static void *ingest_worker(void *p) {
   job *j = (job *)p;
@@ -77,6 +79,8 @@ static void *ingest_worker(void *p) {
   for (uint64_t at = 0; at < j->points; at += batch) {
     const uint32_t m = (uint32_t)(j->points - at < batch ? j->points - at : batch);
     fill(g, recs.data(), m);
+    if (j->hi - j->lo != HASH_SIZE)
+      for (uint32_t i = 0; i < m; i++) recs[i].x[2] = (recs[i].x[2] & ~(uint64_t)HASH_MASK) | (j->lo + (recs[i].x[2] & HASH_MASK) % (j->hi - j->lo));
     uint32_t ne = 0;
     kng_ht_ingest(table, recs.data(), m, off2, NULL, 0, &ne);
     done_points += m;
@@ -89,7 +93,8 @@ int main(int argc, char **argv) {
     fprintf(stderr, "usage: %s add|ingest <points> <report-every> [threads]\n", argv[0]);
     return 2;
   }
-  const bool ingest = !strcmp(argv[1], "ingest");
+  const bool partitioned = !strcmp(argv[1], "ingestp");
+  const bool ingest = !strcmp(argv[1], "ingest") || partitioned;
   const uint64_t points = strtoull(argv[2], NULL, 0), step = strtoull(argv[3], NULL, 0);
   const int threads = argc > 4 ? atoi(argv[4]) : 1;
   Secp256K1 *secp = new Secp256K1();
@@ -139,7 +144,11 @@ int main(int argc, char **argv) {
   std::vector<job> jobs(threads);
   std::vector<pthread_t> tid(threads);
   for (int t = 0; t < threads; t++) {
-    jobs[t] = {points / threads, 0x9E3779B97F4A7C15ULL * (t + 1)};
+    jobs[t] = {points / threads, 0x9E3779B97F4A7C15ULL * (t + 1), 0, HASH_SIZE};
+    if (partitioned) {
+      jobs[t].lo = (uint32_t)((uint64_t)HASH_SIZE * t / threads);
+      jobs[t].hi = (uint32_t)((uint64_t)HASH_SIZE * (t + 1) / threads);
+    }
     pthread_create(&tid[t], NULL, ingest_worker, &jobs[t]);
   }
   uint64_t last = 0, next_report = step;

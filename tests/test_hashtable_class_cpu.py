@@ -84,10 +84,12 @@ def test_gpu_thread_to_table_thread_queue_without_a_gpu(pushes, threads, cap):
     # round 6: hold for a work-file save -- table frozen, queue beyond its normal bound, producer blocked at the hold bound, the
     # table threads release themselves when the generation is finished, events carry the tag of their push
     assert lines[2].startswith("hold: table frozen") and lines[2].endswith(" CONSISTENT"), lines[2]
+    assert lines[3] == "tables: 2 x 20 alive at once, released and deleted CONSISTENT"  # (16 registry slots aborted here in round 5)
     import re
 
     m = re.search(r"high water (\d+) / (\d+) of (\d+) blocked ([0-9.]+) s", lines[0])
-    assert int(m.group(1)) <= cap and int(m.group(2)) <= cap
+    bound = max(cap, 2 * threads)  # a push is cut into one chunk per table thread: the bound is at least two chunks per thread
+    assert int(m.group(3)) == bound and int(m.group(1)) <= bound and int(m.group(2)) <= bound
     if cap <= 4:
         assert float(m.group(4)) > 0.0      # ~20 000 points per push against 1-3 table threads: the producer had to wait
 

@@ -160,8 +160,44 @@ def summarise(h):
             "simd_cycles_model": 4 * slow + 2 * fast}
 
 
+def resources(path):
+    """Per walk kernel of a `hipcc -S` listing: what the code object's descriptor says (VGPRs, LDS, scratch bytes per lane) and
+    where its scratch instructions are -- inside the generated asm statement (the per-kangaroo loop: must be none) or in the
+    compiler's code around it (the inversion tree, the entry pass, the exact path).  VERDICT r5 weak 1: the headline kernel
+    sits at the 2-waves-per-SIMD ceiling (256 VGPRs) WITH spills; they must stay out of the loop."""
+    txt = open(path).read()
+    desc = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", txt, re.S):
+        g = lambda k: int((re.search(r"\.amdhsa_" + k + r"\s+(\S+)", m.group(2)) or [None, "0"])[1], 0)  # noqa: E731
+        desc[m.group(1)] = {"vgprs": g("next_free_vgpr"), "sgprs": g("next_free_sgpr"), "lds_bytes": g("group_segment_fixed_size"),
+                            "scratch_bytes_per_lane": g("private_segment_fixed_size")}
+    for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", txt):
+        if m.group(1) in desc:
+            desc[m.group(1)]["vgpr_spill_count"] = int(m.group(2))
+    out, cur, inasm, blk = {}, None, False, 0
+    for l in txt.split("\n"):
+        m = re.match(r"^(_Z\w+|kng_\w+):", l)
+        if m:
+            cur = m.group(1)
+            out[cur] = dict(desc.get(cur, {}), scratch_ops_in_asm_statements=0, scratch_ops_outside=0, asm_statements_over_500_lines=0)
+        if cur is None:
+            continue
+        if ";;#ASMSTART" in l:
+            inasm, blk = True, 0
+            continue
+        if ";;#ASMEND" in l:
+            inasm = False
+            out[cur]["asm_statements_over_500_lines"] += blk > 500
+            continue
+        blk += inasm
+        if re.search(r"\bscratch_(load|store)", l):
+            out[cur]["scratch_ops_in_asm_statements" if inasm else "scratch_ops_outside"] += 1
+    return {k: v for k, v in out.items() if "walk" in k}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--resources", action="store_true", help="registers / LDS / scratch of every walk kernel and where its scratch instructions are")
     ap.add_argument("--kernel", default="kng_walk_share_kernelILi8ELb1ELb0",
                     help="mangled-name substring; <SHARE, DSPLIT, ASM> = ILi8ELb1ELb0 is the compiler-scheduled loop of the default geometry")
     ap.add_argument("--src", default=os.path.join(ROOT, "kangaroo_amd", "csrc", "kng_engine.hip"))
@@ -170,6 +206,13 @@ def main():
     ap.add_argument("-D", action="append", default=[])
     ap.add_argument("--top", type=int, default=40)
     a = ap.parse_args()
+    if a.resources:
+        path = a.asm or compile_s(a.src, a.D)
+        for k, v in resources(path).items():
+            print(k, v)
+        if not a.asm:
+            os.unlink(path)
+        return
     if re.search(r"kng_walk_share_kernelILi\dELb[01]ELb1", a.kernel):
         # ASM = true: the per-kangaroo loop is ONE generated asm statement (kng_walk_asm.h) that LLVM's loop annotations do not
         # see -- the loop this tool would find is the compiler-scheduled one of a launch's last step.  The generator prints the
