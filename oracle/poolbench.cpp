@@ -65,8 +65,10 @@ int main(int argc, char **argv) {
   printf("# HashTable_kng.o behind kng_ingest.h: %d owner-partitioned table threads, %d producers, %u points per push\n", W, P, per_push);
   printf("# %12s %14s %22s %10s\n", "entries", "points/s", "ns/point/table-thread", "rss MB");
   std::atomic<int> alive{P};
-  std::vector<std::atomic<uint64_t>> busy_ns((size_t)P);
+  std::vector<std::atomic<uint64_t>> busy_ns((size_t)P), done_pts((size_t)P);
   for (auto &b : busy_ns) b = 0;
+  for (auto &b : done_pts) b = 0;
+  const double t_start = now();
   for (int p = 0; p < P; p++)
     th.emplace_back([&, p] {
       kng_ingest::Ingest ing(ht, off2, W, 64 * (size_t)(per_push / kng_ingest::CHUNK + 1));
@@ -87,21 +89,27 @@ int main(int argc, char **argv) {
         blocked[(size_t)p] += ing.push(recs.data(), m);
         ing.take_events(ev);
         pushed += m;
-        busy_ns[(size_t)p] = (uint64_t)(ing.totals().busy_s * 1e9);
+        const kng_ingest::Ingest::Totals tt = ing.totals();
+        busy_ns[(size_t)p] = (uint64_t)(tt.busy_s * 1e9);
+        done_pts[(size_t)p] = tt.points;
       }
       ing.flush();
-      busy_ns[(size_t)p] = (uint64_t)(ing.totals().busy_s * 1e9);
+      const kng_ingest::Ingest::Totals tt = ing.totals();
+      busy_ns[(size_t)p] = (uint64_t)(tt.busy_s * 1e9);
+      done_pts[(size_t)p] = tt.points;
       alive--;
     });
+  /* both columns count points the table threads have FINISHED (the producers run ahead by what the queues hold) */
   uint64_t last = 0, next_report = step, last_busy = 0;
   double tl = now();
-  while (alive.load() > 0 || last < pushed.load()) {
+  for (;;) {
     usleep(20000);
-    const uint64_t d = pushed.load();
-    if (d >= next_report || alive.load() == 0) {
+    uint64_t d = 0, b = 0;
+    for (auto &x : done_pts) d += x.load();
+    for (auto &x : busy_ns) b += x.load();
+    const bool over = alive.load() == 0;
+    if (d >= next_report || over) {
       const double t = now();
-      uint64_t b = 0;
-      for (auto &x : busy_ns) b += x.load();
       if (d > last)
         printf("  %12" PRIu64 " %14.0f %22.1f %10.0f\n", ht->GetNbItem(), (d - last) / (t - tl), (double)(b - last_busy) / (double)(d - last), rss_mb());
       fflush(stdout);
@@ -109,12 +117,13 @@ int main(int argc, char **argv) {
       last_busy = b;
       tl = t;
       next_report = d + step;
-      if (alive.load() == 0) break;
+      if (over) break;
     }
   }
   for (std::thread &t : th) t.join();
   double bl = 0;
   for (double v : blocked) bl += v;
-  printf("# producers blocked for queue room %.3f s in total; %" PRIu64 " entries\n", bl, ht->GetNbItem());
+  printf("# %" PRIu64 " entries in %.2f s = %.1f M points/s over the whole run; producers blocked for queue room %.3f s in total\n", ht->GetNbItem(),
+         now() - t_start, (double)ht->GetNbItem() / (now() - t_start) / 1e6, bl);
   return 0;
 }
