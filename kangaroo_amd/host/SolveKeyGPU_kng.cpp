@@ -118,11 +118,19 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
     ::fprintf(stderr, "SolveKeyGPU_kng: herd creation on the device failed (%s); creating the kangaroos on the host\n", kng_last_error());
     return false;
   };
+  // the 3 x N `Int` of the reference's interface: only the host-side herd, KNG_REF_SAVE and KNG_SAVE_VERIFY still use them
+  auto needArrays = [&]() {
+    Int **a[3] = {&ph->px, &ph->py, &ph->distance};
+    for (Int **q : a)
+      if (*q == NULL) *q = new Int[ph->nbKangaroo];
+  };
+  auto dropArrays = [&]() {
+    Int **a[3] = {&ph->px, &ph->py, &ph->distance};
+    for (Int **q : a) safe_delete_array(*q);
+  };
   auto hostHerd = [&]() { // Kangaroo.cpp:529-541: one block of GPU_GRP_SIZE per GPU thread, tame first
     const uint64_t nbThread = gpu->GetNbThread();
-    ph->px = new Int[ph->nbKangaroo];
-    ph->py = new Int[ph->nbKangaroo];
-    ph->distance = new Int[ph->nbKangaroo];
+    needArrays();
     for (uint64_t i = 0; i < nbThread; i++)
       CreateHerd(GPU_GRP_SIZE, &(ph->px[i * GPU_GRP_SIZE]), &(ph->py[i * GPU_GRP_SIZE]), &(ph->distance[i * GPU_GRP_SIZE]), TAME);
     gpu->SetKangaroos(ph->px, ph->py, ph->distance);
@@ -179,10 +187,7 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
       createHerd();
     }
   }
-  // nobody asks for the kangaroos back through these arrays any more (KNG_REF_SAVE / KNG_SAVE_VERIFY allocate them when needed)
-  safe_delete_array(ph->px);
-  safe_delete_array(ph->py);
-  safe_delete_array(ph->distance);
+  dropArrays(); // nobody asks for the kangaroos back through them any more (KNG_REF_SAVE / KNG_SAVE_VERIFY allocate them when needed)
 
   gpu->callKernel();
 
@@ -257,11 +262,7 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
       const double ts = Timer::get_tick();
       if (savePointNow && saveKangaroo) {
         if (refSave || verifySave) { // the reference's way, for comparison: 3 x N Int through GPUEngine::GetKangaroos
-          if (ph->px == NULL) {
-            ph->px = new Int[ph->nbKangaroo];
-            ph->py = new Int[ph->nbKangaroo];
-            ph->distance = new Int[ph->nbKangaroo];
-          }
+          needArrays();
           gpu->GetKangaroos(ph->px, ph->py, ph->distance);
         }
         if (!refSave) {
@@ -364,9 +365,7 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
     if (getenv("KNG_STATS")) report("");
   } // ~Ingest: table threads joined, whatever was still queued is dropped (the search is over)
 
-  safe_delete_array(ph->px);
-  safe_delete_array(ph->py);
-  safe_delete_array(ph->distance);
+  dropArrays();
   delete gpu;
 
   ph->isRunning = false;

@@ -227,3 +227,47 @@ def test_dp_capacity_can_be_raised_between_launches(kng, orc):
     key = lambda r: (int(r["kidx"]), tuple(int(v) for v in r["x"]), tuple(int(v) for v in r["d"]))  # noqa: E731
     assert eng.lastLost == 0 and total == len(got) and sorted(map(key, got)) == sorted(map(key, want))
     eng.close()
+
+
+@pytest.mark.parametrize("ring", [1, 0])
+def test_refused_capacity_growth_keeps_the_engine_walking_into_its_old_buffers(kng, orc, monkeypatch, ring):
+    """kng_reserve_points used to free the DP buffers before it had the bigger ones; a refused allocation (a pinned
+    ring against a memlock limit) then left the device-side loop arguments pointing at freed memory while GPUEngine::SetParams
+    carried on ("keeping %u").  Now the new set is obtained first.  KNG_TEST_FAIL_RESERVE=1 refuses every growth: the call
+    fails with KNG_E_ALLOC, the capacity and the buffers stay, and the launches after it deliver the oracle's points -- through
+    the scheduled loop, whose arguments live on the device, in both landing modes."""
+    import ctypes as C
+
+    from helpers import ints_to_array
+    from test_gpu_parity import _seeded_herd
+
+    lib = kng.load_library()
+    lib.kng_reserve_points.argtypes = [C.c_void_p, C.c_uint32]
+    grid, rp = (2, 2), 72
+    n = grid[0] * grid[1] * 128
+    x, y, true_d, woff = _seeded_herd(orc, n, rp, seed=777)
+    jd, jx, jy, _ = orc.jump_table(rp)
+    mask = orc.dp_mask(5)
+    with kng.GPUEngine(grid[0], grid[1], 0, 4096, dp_ring=ring, asm=1) as eng:
+        eng.SetParams(mask, jd, jx, jy)
+        eng.SetWildOffset(woff)
+        eng.SetKangaroos(x, y, ints_to_array(true_d))
+        eng.callKernel()
+        eng.wait()
+        eng.drain(raw=True)
+        monkeypatch.setenv("KNG_TEST_FAIL_RESERVE", "1")
+        assert lib.kng_reserve_points(eng._h, 1 << 20) == -2  # KNG_E_ALLOC
+        assert b"refused" in lib.kng_last_error()
+        monkeypatch.delenv("KNG_TEST_FAIL_RESERVE")
+        assert eng.get_option("max_found") == 4096
+        gx, gy, gd = eng.GetKangaroos(raw=True)
+        ox, oy, od = gx.copy(), gy.copy(), gd.copy()
+        key = lambda r: (int(r["kidx"]), tuple(int(v) for v in r["x"]), tuple(int(v) for v in r["d"]))  # noqa: E731
+        for _ in range(3):  # both launch slots
+            eng.callKernel()
+            eng.wait()
+            got = eng.drain(raw=True)
+            want, total = orc.walk(ox, oy, od, 64, jd, jx, jy, mask, dp_cap=1 << 20)
+            assert eng.lastLost == 0 and total == len(got) and sorted(map(key, got)) == sorted(map(key, want))
+        # ... and a growth that IS granted still works afterwards
+        assert lib.kng_reserve_points(eng._h, 1 << 16) == 0 and eng.get_option("max_found") == 1 << 16
