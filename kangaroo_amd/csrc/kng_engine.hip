@@ -376,8 +376,8 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch, InvRing
                 put(w, pre);
             }
             __syncthreads();
-            // ONE inversion, on three waves (kng_modinv.h): wave 0 leads -- division steps on the low limbs --, wave 2 applies the
-            // matrices to f, g, wave 1 to d, e, ending up with t = 1 / (pre0 * pre1).  Round 5: wave 0 alone, waves 1-3 at the
+            // ONE inversion, on two waves (kng_modinv.h): wave 0 leads -- division steps and f, g --, wave 1 follows one
+            // round behind with d, e and ends up holding t = 1 / (pre0 * pre1).  Round 5: wave 0 alone, waves 1-3 at the
             // barrier: the 64 inversions of a launch of such a herd ARE the launch (1.91 ms of 1.91 ms at 65 536 kangaroos).
 #ifdef KNG_INV_ONE_WAVE // measurement builds only (tools/build_variant.sh): round 5's form, wave 0 inverts alone
             if (w == 0) {
@@ -396,8 +396,6 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch, InvRing
                 const fe p0 = get(0);
                 put(0, fe_mul(t, pre)); // 1/pre0 (pre = this wave's own pair product)
                 i = fe_mul(t, p0);      // 1/pre1
-            } else if (w == 2) {
-                fe_inv_follow_fg(ring);
             }
             __syncthreads();
             if (w == 0) i = get(0);
@@ -495,7 +493,7 @@ __global__ void __launch_bounds__(SHARE == 8 ? 512 : 256) __attribute__((amdgpu_
     __shared__ typename std::conditional<SHARE == 4, InvRing, uint32_t>::type ring_mem;
     InvRing *const ring = reinterpret_cast<InvRing *>(&ring_mem);
     for (uint32_t i = threadIdx.x; i < JT_WORDS; i += blockDim.x) tab[i] = a.jtab[i];
-    if (SHARE == 4 && threadIdx.x == 0) ring->progress = ring->fg_done = ring->stop = ring->sf_ready = 0;
+    if (SHARE == 4 && threadIdx.x == 0) ring->progress = 0;
     __syncthreads();
     walk_body<SHARE, DSPLIT, ASM>(a, tab, xch, ring);
 }

@@ -230,28 +230,21 @@ KNG_DEV_NOINLINE fe fe_inv(const fe &a_in) {
 }
 
 #if defined(__HIPCC__)
-// ---- one inversion, three waves (round 6; small herds: a launch of 65 536 kangaroos is 64 SERIAL inversions).
+// ---- one inversion, two waves (round 6; small herds: a launch of 65 536 kangaroos is 64 SERIAL inversions).
 // A lone wave issues one dependent VALU instruction every ~5 cycles, so the latency of fe_inv is its instruction count: per
 // round 360 for the 30 division steps, ~80 for (f, g) <- t (f, g) / 2^30, ~115 for (d, e) <- t (d, e) / 2^30 mod p.  Only the
-// division steps are inherently serial, and all they need of f and g is the low 60 bits:
-//   LEAD       division steps on the low two limbs, publishes the round's matrix, then computes ONLY the two low limbs of the
-//              new f, g -- three columns of the product, for which it borrows limb 2 of the previous f, g from the wave below;
-//   FOLLOW-FG  applies every matrix to the full nine limbs, one round behind, hands limb 2 back, notices when g = 0 in every
-//              lane (the rounds that remain would change nothing) and ends with the sign of f;
-//   FOLLOW-DE  applies every matrix to d, e (nobody needs them before the end) and finishes the result.
-// The followers are waves of the same block, on other SIMDs, idle at the barrier otherwise.  Same arithmetic, same result as
-// fe_inv (a round more than needed multiplies d by 2^30 * 2^-30 -- the fixed point fe_inv itself relies on for lanes that
-// finish before the slowest of their wave); ~30 % less latency: 1.91 -> 1.69 ms per launch with two waves
-// (profiles/r06_small_herd_split_ab.txt), -> see DESIGN.md for three.
+// first two are on the critical path: the division steps of round r + 1 need f, g of round r, nobody needs d, e before the
+// end.  The LEAD wave therefore runs division steps + update_fg30 and publishes each round's matrix in LDS; the FOLLOW wave --
+// another wave of the block, on another SIMD, idle at the barrier otherwise -- applies the matrices to d, e one round behind
+// and finishes with the sign of f.  Same arithmetic, same result as fe_inv; 1.917 -> 1.72 ms per launch at 65 536 kangaroos.
+// (Measured and NOT adopted: a third wave applying the matrices to f, g as well, the lead keeping only the three low limbs
+// and borrowing limb 2 back every round -- the LDS round trip on the lead's critical path costs more than the 50 instructions
+// it saves: 1.81 ms, and 1.90 ms with the reads issued between the two halves of the division steps;
+// profiles/r06_small_herd_waves_ab.txt.)
 struct InvRing {
-    int32_t m[20][4][64];  // u, v, q, r of every round, per lane of the lead wave
-    uint64_t a[4][64];     // the operand, for FOLLOW-FG
-    int32_t fg2[2][2][64]; // limb 2 of f / g after round r, slot r & 1
-    int32_t sf[64];        // sign of the final f
-    uint32_t progress;     // LEAD: rounds published so far; | 0x100 once it has left its loop
-    uint32_t fg_done;      // FOLLOW-FG: rounds applied; 0xFF once it has stopped
-    uint32_t stop;         // FOLLOW-FG: g == 0 in every lane after this many rounds (0 = not yet)
-    uint32_t sf_ready;     // FOLLOW-FG: sf[] written.  FOLLOW-DE, the last to finish, resets all four.
+    int32_t m[20][4][64]; // u, v, q, r of every round, per lane of the lead wave
+    int32_t sf[64];       // sign of the final f
+    uint32_t progress;    // rounds published so far; | 0x100 once the lead has left its loop.  The follow wave resets it.
 };
 #define KNG_RING_LOAD(p) __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define KNG_RING_STORE(p, v) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -271,85 +264,30 @@ KNG_DEV void fe_to30(const fe &a, int32_t g[9]) {
 KNG_DEV void fe_inv_lead(const fe &a_in, InvRing *ring) {
     const fe a = fe_canon(a_in);
     const uint32_t lane = threadIdx.x & 63;
+    int32_t f[9], g[9];
 #pragma unroll
-    for (int k = 0; k < 4; k++) ring->a[k][lane] = a.v[k]; // (visible to FOLLOW-FG with the first `progress`)
-    int32_t f0 = p30(0), f1 = p30(1), f2 = p30(2);
-    int32_t g0 = (int32_t)(a.v[0] & M30), g1 = (int32_t)((a.v[0] >> 30) & M30), g2 = (int32_t)(((a.v[0] >> 60) | (a.v[1] << 4)) & M30);
+    for (int i = 0; i < 9; i++) f[i] = p30(i);
+    fe_to30(a, g);
     int32_t zeta = -1;
     uint32_t rounds = 0;
 #pragma unroll 1
     for (int it = 0; it < 20; it++) {
         int32_t u, v, q, r;
-        zeta = divsteps30(zeta, (uint32_t)f0 | ((uint32_t)f1 << 30), (uint32_t)g0 | ((uint32_t)g1 << 30), u, v, q, r);
+        zeta = divsteps30(zeta, (uint32_t)f[0] | ((uint32_t)f[1] << 30), (uint32_t)g[0] | ((uint32_t)g[1] << 30), u, v, q, r);
         ring->m[it][0][lane] = u;
         ring->m[it][1][lane] = v;
         ring->m[it][2][lane] = q;
         ring->m[it][3][lane] = r;
         rounds = (uint32_t)it + 1;
         if (lane == 0) KNG_RING_STORE(&ring->progress, rounds);
-        if (it > 0) {
-            // limb 2 of f, g as they were BEFORE this round: FOLLOW-FG wrote them a whole round of division steps ago
-            while (KNG_RING_LOAD(&ring->fg_done) < (uint32_t)it) __builtin_amdgcn_s_sleep(1);
-            if (KNG_RING_LOAD(&ring->stop)) break; // g = 0 everywhere: this round's matrix changes nothing, and nothing is left to do
-            f2 = ring->fg2[(it - 1) & 1][0][lane];
-            g2 = ring->fg2[(it - 1) & 1][1][lane];
-        }
-        // the two low limbs of (f, g) <- t (f, g) / 2^30: columns 0, 1, 2 of the product
-        int64_t cf = 0, cg = 0;
-        KNG_FG_STEP(cf, cg, u, v, q, r, f0, g0);
-        cf >>= 30;
-        cg >>= 30;
-        KNG_FG_STEP(cf, cg, u, v, q, r, f1, g1);
-        f0 = (int32_t)cf & M30;
-        g0 = (int32_t)cg & M30;
-        cf >>= 30;
-        cg >>= 30;
-        KNG_FG_STEP(cf, cg, u, v, q, r, f2, g2);
-        f1 = (int32_t)cf & M30;
-        g1 = (int32_t)cg & M30;
-    }
-    if (lane == 0) KNG_RING_STORE(&ring->progress, rounds | 0x100u);
-}
-
-KNG_DEV void fe_inv_follow_fg(InvRing *ring) {
-    const uint32_t lane = threadIdx.x & 63;
-    while ((KNG_RING_LOAD(&ring->progress) & 0xFFu) == 0) __builtin_amdgcn_s_sleep(1);
-    fe a;
+        update_fg30(f, g, u, v, q, r);
+        uint32_t nz = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) a.v[k] = ring->a[k][lane];
-    int32_t f[9], g[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) f[i] = p30(i);
-    fe_to30(a, g);
-    uint32_t done = 0;
-#pragma unroll 1
-    for (;;) {
-        const uint32_t pr = KNG_RING_LOAD(&ring->progress);
-        if ((pr & 0xFFu) > done) {
-            const int32_t u = ring->m[done][0][lane], v = ring->m[done][1][lane], q = ring->m[done][2][lane], r = ring->m[done][3][lane];
-            update_fg30(f, g, u, v, q, r);
-            ring->fg2[done & 1][0][lane] = f[2];
-            ring->fg2[done & 1][1][lane] = g[2];
-            done++;
-            uint32_t nz = 0;
-#pragma unroll
-            for (int i = 0; i < 9; i++) nz |= (uint32_t)g[i];
-            if (__ballot(nz != 0) == 0) { // wave-uniform, as in fe_inv: every lane is at the fixed point
-                if (lane == 0) {
-                    KNG_RING_STORE(&ring->stop, done);     // first: a lead that gets past its wait from now on sees it
-                    KNG_RING_STORE(&ring->fg_done, 0xFFu); // ... and no lead waits for a round this wave will not apply
-                }
-                break;
-            }
-            if (lane == 0) KNG_RING_STORE(&ring->fg_done, done);
-        } else if (pr & 0x100u) {
-            break;
-        } else {
-            __builtin_amdgcn_s_sleep(1);
-        }
+        for (int i = 0; i < 9; i++) nz |= (uint32_t)g[i];
+        if (__ballot(nz != 0) == 0) break; // (wave-uniform, as in fe_inv)
     }
     ring->sf[lane] = f[8] >> 31;
-    if (lane == 0) KNG_RING_STORE(&ring->sf_ready, 1u);
+    if (lane == 0) KNG_RING_STORE(&ring->progress, rounds | 0x100u);
 }
 
 KNG_DEV fe fe_inv_follow(InvRing *ring) {
@@ -381,16 +319,9 @@ KNG_DEV fe fe_inv_follow(InvRing *ring) {
             __builtin_amdgcn_s_sleep(1);
         }
     }
-    while (KNG_RING_LOAD(&ring->sf_ready) == 0) __builtin_amdgcn_s_sleep(1);
     const int32_t sf = ring->sf[lane];
-    // the lead has left its loop, FOLLOW-FG has written the sign, this wave has read everything: the ring is free for the next
-    // inversion (two barriers away)
-    if (lane == 0) {
-        KNG_RING_STORE(&ring->fg_done, 0u);
-        KNG_RING_STORE(&ring->stop, 0u);
-        KNG_RING_STORE(&ring->sf_ready, 0u);
-        KNG_RING_STORE(&ring->progress, 0u);
-    }
+    // the lead has left its loop and this wave has read everything: the ring is free for the next inversion (two barriers away)
+    if (lane == 0) KNG_RING_STORE(&ring->progress, 0u);
     // result = sign(f) * d mod p, d in (-2p, p): the tail of fe_inv
     int32_t cond = d[8] >> 31;
     int32_t c = 0;
