@@ -286,3 +286,80 @@ def test_work_file_saves_without_verify_cost_nothing_and_restore_streams(kng, tm
     assert c1 < c2 < c3 < c4, (c1, c2, c3, c4)
     chk = subprocess.run([ref, "-t", "16", "-wcheck", str(w4)], capture_output=True, text=True, timeout=900).stdout
     assert "100.000% OK" in chk, chk[-500:]
+
+
+_P72 = "49DCCFD96DC5DF56487436F5A1B18C4F5D34F65DDB48CB"  # 46 hex digits + 18 = a 72-bit interval: not solved within a test
+IN64 = _P72 + "0" * 18 + "\n" + _P72 + "F" * 18 + "\n0259A3BFDAD718C9D3FAC7C187F1139F0815AC5D923910D516E186AFDA28B221DC\n"
+
+
+def _winfo(ref, path):
+    info = subprocess.run([ref, "-winfo", str(path)], capture_output=True, text=True, timeout=300).stdout
+    return info, int(re.search(r"Kangaroos\s*:\s*(\d+)", info).group(1)), int(re.search(r"Count\s*:\s*(\d+)", info).group(1))
+
+
+def test_work_file_of_two_gpu_threads_and_two_cpu_threads(tmp_path):
+    """Thread order of the kangaroo section (Backup.cpp:525-536: CPU threads first, then GPU threads): `-t 2 -gpu -gpuId 0,0` -- two
+    parked CPU threads written from their arrays, two GPU threads streamed from their snapshots while they walk on.  The
+    unmodified program reads the file, restores it into the same thread layout and continues; ours restores the unmodified
+    program's file of that layout."""
+    exe, ref = ref_binary("kangaroo_mi355x"), ref_binary("kangaroo_hip")
+    cfg = tmp_path / "in72.txt"
+    cfg.write_text(IN64)
+    base = ["-t", "2", "-gpu", "-gpuId", "0,0", "-g", "32,128,48,128", "-d", "12"]
+    nk = 2 * 1024 + (32 + 48) * 128 * 128
+    w1, w2, w3 = tmp_path / "a.work", tmp_path / "b.work", tmp_path / "c.work"
+    t1 = _run([exe] + base + ["-ws", "-w", str(w1), "-wi", "4", str(cfg)], 30, env={"KNG_STATS": "1", "KNG_SAVE_VERIFY": "1"}, until="done [")
+    assert "done [" in t1, t1[-2000:]
+    ver = re.findall(r"SaveWork_kng verify: (\d+) streamed kangaroos, (\d+) differ", t1)
+    assert ver and int(ver[0][0]) == (32 + 48) * 128 * 128 and int(ver[0][1]) == 0, (ver, t1[-1500:])
+    _, k1, c1 = _winfo(ref, w1)
+    assert k1 == nk
+    chk = subprocess.run([ref, "-t", "8", "-wcheck", str(w1)], capture_output=True, text=True, timeout=600).stdout
+    assert "100.000% OK" in chk, chk[-500:]
+    t2 = _run([ref] + base + ["-i", str(w1), "-ws", "-w", str(w2), "-wi", "4", str(cfg)], 40, until="done [")
+    assert "done [" in t2 and "[0 created]" in t2, t2[-2000:]
+    _, k2, c2 = _winfo(ref, w2)
+    t3 = _run([exe] + base + ["-i", str(w2), "-ws", "-w", str(w3), "-wi", "4", str(cfg)], 40, env={"KNG_STATS": "1"}, until="done [")
+    assert "done [" in t3 and "[0 created]" in t3, t3[-2000:]
+    _, k3, c3 = _winfo(ref, w3)
+    assert k2 == k3 == nk and c1 < c2 < c3
+
+
+def test_split_work_files_and_saves_without_kangaroos(tmp_path):
+    """`-wsplit`: every save goes to its own file and empties the table (Backup.cpp:470-472, :550-551) -- with the GPU walking on
+    and its points of the meantime going into the emptied table; `-w f -wi N` without `-ws`: header + table only, through the
+    reference's own SaveWork (delegated), the GPU thread only pausing its table threads for it; KNG_REF_SAVE=1: the reference's own
+    save code with the GPU thread filling `Int` arrays as it used to -- all three readable by the unmodified program."""
+    exe, ref = ref_binary("kangaroo_mi355x"), ref_binary("kangaroo_hip")
+    cfg = tmp_path / "in72.txt"
+    cfg.write_text(IN64)
+    base = [exe, "-t", "0", "-gpu", "-g", "64,128", "-d", "12"]
+    nk = 64 * 128 * 128
+    d = tmp_path / "split"
+    d.mkdir()
+    t = _run(base + ["-ws", "-wsplit", "-w", str(d / "w"), "-wi", "3", str(cfg)], 14, env={"KNG_STATS": "1"})
+    files = sorted(os.listdir(d))
+    assert len(files) >= 2 and t.count("done [") >= 2, (files, t[-1500:])
+    counts = []
+    for f in files[:3]:
+        info, k, c = _winfo(ref, d / f)
+        assert k == nk
+        counts.append(int(re.search(r"DP Count\s*:\s*(\d+)", info).group(1)))
+    # each file holds only the points since the save before it: about interval x rate / 2^dp each, not a growing total
+    assert max(counts[1:]) < 2.5 * min(counts[1:]) + 1000, counts
+    # no -ws: no kangaroos in the file
+    w = tmp_path / "table_only.work"
+    t = _run(base + ["-w", str(w), "-wi", "3", str(cfg)], 9, env={"KNG_STATS": "1"}, until="done [")
+    assert "done [" in t, t[-1500:]
+    _, k, _ = _winfo(ref, w)
+    assert k == 0
+    # the reference's own save path on request
+    w = tmp_path / "refsave.work"
+    t = _run(base + ["-ws", "-w", str(w), "-wi", "3", str(cfg)], 12, env={"KNG_STATS": "1", "KNG_REF_SAVE": "1"}, until="done [")
+    assert "done [" in t and "SaveWork_kng" not in t, t[-1500:]
+    _, k, _ = _winfo(ref, w)
+    assert k == nk
+    chk = subprocess.run([ref, "-t", "8", "-wcheck", str(w)], capture_output=True, text=True, timeout=600).stdout
+    assert "100.000% OK" in chk, chk[-500:]
+    t = _run(base + ["-i", str(w), "-ws", "-w", str(tmp_path / "again.work"), "-wi", "3", str(cfg)], 20, env={"KNG_REF_SAVE": "1"}, until="done [")
+    assert "done [" in t and "Fetch kangaroos" in t, t[-1500:]  # the reference's FetchWalks ran (delegated)
