@@ -1496,6 +1496,7 @@ static void snap_args(const kng_engine *h, SnapArgs &a, uint64_t first, uint64_t
 int kng_snapshot(kng_engine *h, const uint64_t wild_offset[4]) {
     if (!h) return fail(KNG_E_ARG, "null engine");
     if (!h->have_herd) return fail(KNG_E_STATE, "no herd loaded");
+    if (getenv("KNG_TEST_FAIL_SNAPSHOT")) return fail(KNG_E_ALLOC, "snapshot records (%zu bytes): refused (KNG_TEST_FAIL_SNAPSHOT)", 96 * (size_t)h->n); // test hook
     HIP_TRY(hipSetDevice(h->dev));
     if (int rc = snapshot_buffers(h)) return rc;
     // a reader of the previous snapshot must be done before its records are overwritten (the caller's protocol says so;

@@ -197,6 +197,7 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
 
   kng_save::attach(ph, eng);
   uint64_t handled = kng_save::requested.load(); // save generations this thread has dealt with
+  ph->isWaiting = false; // (a thread of the previous key may have ended at a save point: TH_PARAM is reused, Kangaroo.cpp:1041-1047)
   ph->hasStarted = true;
 
   {
@@ -266,8 +267,15 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
           gpu->GetKangaroos(ph->px, ph->py, ph->distance);
         }
         if (!refSave) {
-          if (kng_snapshot(eng, woff) == KNG_OK) kng_save::snapshot_taken(ph, req);
-          else ::fprintf(stderr, "SolveKeyGPU_kng GPU#%d: %s\n", ph->gpuId, kng_last_error()); // SaveWork will say that this thread has nothing to save
+          if (kng_snapshot(eng, woff) == KNG_OK) {
+            kng_save::snapshot_taken(ph, req);
+          } else { // (no room for the second buffer?)  This save goes the reference's way: SaveWork writes from the arrays
+            ::fprintf(stderr, "SolveKeyGPU_kng GPU#%d: %s; saving through GetKangaroos\n", ph->gpuId, kng_last_error());
+            if (!verifySave) {
+              needArrays();
+              gpu->GetKangaroos(ph->px, ph->py, ph->distance);
+            }
+          }
         }
       }
 
@@ -361,6 +369,7 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
       }
     }
 
+    ph->isWaiting = false;
     kng_save::detach(ph); // (waits while a saver is still reading this engine's snapshot)
     if (getenv("KNG_STATS")) report("");
   } // ~Ingest: table threads joined, whatever was still queued is dropped (the search is over)

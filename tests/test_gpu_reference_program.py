@@ -363,3 +363,21 @@ def test_split_work_files_and_saves_without_kangaroos(tmp_path):
     assert "100.000% OK" in chk, chk[-500:]
     t = _run(base + ["-i", str(w), "-ws", "-w", str(tmp_path / "again.work"), "-wi", "3", str(cfg)], 20, env={"KNG_REF_SAVE": "1"}, until="done [")
     assert "done [" in t and "Fetch kangaroos" in t, t[-1500:]  # the reference's FetchWalks ran (delegated)
+
+
+def test_a_refused_snapshot_buffer_falls_back_to_the_arrays(tmp_path):
+    """The second device buffer (96 B x herd) can be refused on a device that is nearly full.  The GPU thread then fills the
+    reference-shaped `Int` arrays at the same launch boundary and SaveWork_kng writes that thread's section from them: the file
+    is complete and the unmodified program checks it (KNG_TEST_FAIL_SNAPSHOT=1 refuses every snapshot)."""
+    exe, ref = ref_binary("kangaroo_mi355x"), ref_binary("kangaroo_hip")
+    cfg = tmp_path / "in72.txt"
+    cfg.write_text(IN64)
+    w = tmp_path / "fallback.work"
+    t = _run([exe, "-t", "0", "-gpu", "-g", "64,128", "-d", "12", "-ws", "-w", str(w), "-wi", "3", str(cfg)], 12,
+             env={"KNG_STATS": "1", "KNG_TEST_FAIL_SNAPSHOT": "1"}, until="done [")
+    assert "done [" in t and "saving through GetKangaroos" in t and "FAILED" not in t, t[-2000:]
+    assert re.search(r"SaveWork_kng: .* 1048576 kangaroos \(0 streamed from device snapshots\)", t), t[-1500:]
+    _, k, _ = _winfo(ref, w)
+    assert k == 64 * 128 * 128
+    chk = subprocess.run([ref, "-t", "8", "-wcheck", str(w)], capture_output=True, text=True, timeout=600).stdout
+    assert "100.000% OK" in chk, chk[-500:]
