@@ -288,8 +288,7 @@ def test_work_file_saves_without_verify_cost_nothing_and_restore_streams(kng, tm
     assert "100.000% OK" in chk, chk[-500:]
 
 
-_P72 = "49DCCFD96DC5DF56487436F5A1B18C4F5D34F65DDB48CB"  # 46 hex digits + 18 = a 72-bit interval: not solved within a test
-IN64 = _P72 + "0" * 18 + "\n" + _P72 + "F" * 18 + "\n0259A3BFDAD718C9D3FAC7C187F1139F0815AC5D923910D516E186AFDA28B221DC\n"
+IN64 = IN80  # (name kept by the tests below) the 80-bit interval with a key OUTSIDE it: no test run can end by solving it
 
 
 def _winfo(ref, path):
@@ -303,7 +302,7 @@ def test_work_file_of_two_gpu_threads_and_two_cpu_threads(tmp_path):
     unmodified program reads the file, restores it into the same thread layout and continues; ours restores the unmodified
     program's file of that layout."""
     exe, ref = ref_binary("kangaroo_mi355x"), ref_binary("kangaroo_hip")
-    cfg = tmp_path / "in72.txt"
+    cfg = tmp_path / "in80b.txt"
     cfg.write_text(IN64)
     base = ["-t", "2", "-gpu", "-gpuId", "0,0", "-g", "32,128,48,128", "-d", "12"]
     nk = 2 * 1024 + (32 + 48) * 128 * 128
@@ -331,7 +330,7 @@ def test_split_work_files_and_saves_without_kangaroos(tmp_path):
     reference's own SaveWork (delegated), the GPU thread only pausing its table threads for it; KNG_REF_SAVE=1: the reference's own
     save code with the GPU thread filling `Int` arrays as it used to -- all three readable by the unmodified program."""
     exe, ref = ref_binary("kangaroo_mi355x"), ref_binary("kangaroo_hip")
-    cfg = tmp_path / "in72.txt"
+    cfg = tmp_path / "in80b.txt"
     cfg.write_text(IN64)
     base = [exe, "-t", "0", "-gpu", "-g", "64,128", "-d", "12"]
     nk = 64 * 128 * 128
@@ -370,7 +369,7 @@ def test_a_refused_snapshot_buffer_falls_back_to_the_arrays(tmp_path):
     reference-shaped `Int` arrays at the same launch boundary and SaveWork_kng writes that thread's section from them: the file
     is complete and the unmodified program checks it (KNG_TEST_FAIL_SNAPSHOT=1 refuses every snapshot)."""
     exe, ref = ref_binary("kangaroo_mi355x"), ref_binary("kangaroo_hip")
-    cfg = tmp_path / "in72.txt"
+    cfg = tmp_path / "in80b.txt"
     cfg.write_text(IN64)
     w = tmp_path / "fallback.work"
     t = _run([exe, "-t", "0", "-gpu", "-g", "64,128", "-d", "12", "-ws", "-w", str(w), "-wi", "3", str(cfg)], 12,

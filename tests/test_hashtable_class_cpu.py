@@ -122,3 +122,11 @@ def test_link_time_replacements_are_really_linked_in():
         assert f" T {alias}" in full and alias not in hip and alias not in ht, alias
     assert "kng_snapshot_read" in full and "kng_snapshot_read" not in hip
     assert "kng_drain_view" not in hip   # the reference's loop goes through GPUEngine::Launch (kng_drain)
+
+
+def test_pool_of_owner_partitioned_table_threads_end_to_end():
+    """oracle/poolbench.cpp (the measurement tool behind INTEGRATION.md's `-d` table) on a small count: two producers route
+    300 000 uniform points to three table threads by bucket ownership; every point ends in the table."""
+    lines = _run(ref_binary("poolbench"), 300000, 100000, 3, 2, 20000)
+    assert lines[0].startswith("# HashTable_kng.o behind kng_ingest.h: 3 owner-partitioned table threads, 2 producers")
+    assert lines[-1].startswith("# 300000 entries in "), lines[-1]

@@ -18,13 +18,13 @@ echo "== bench"; python bench.py 2> $OUT/${TAG}_bench.err | tee $OUT/${TAG}_benc
 echo "== bench --gpus 2 on this one device is not possible; host path at the 8-GPU DP rate instead"
 [ -x tools/dp_ingest_bench ] && (./tools/dp_ingest_bench --feeders 8 --launches 60 --launch-ms 21; ./tools/dp_ingest_bench --feeders 8 --launches 60) | tee $OUT/${TAG}_dp_ingest.txt
 echo "== rocprofv3 kernel trace"
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o kt -- python $OLDPWD/bench.py --no-cpu-baseline --no-pipeline --no-secondary > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o kt -- python $OLDPWD/bench.py --no-cpu-baseline --no-pipeline --no-secondary --no-pmc > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err)
 find $OUT/${TAG}_prof -name "*kernel_stats*" | head -3
 for f in $(find $OUT/${TAG}_prof -name "*kernel_stats.csv"); do cp $f $OUT/${TAG}_kernel_stats.csv; done
 cat $OUT/${TAG}_kernel_stats.csv 2>/dev/null | head -8
 echo "== rocprofv3 PMC passes (counters only)"
 for C in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && rocprofv3 --pmc $C --output-format csv -d $OUT/${TAG}_pmc_$C -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-secondary > /dev/null 2> $OUT/${TAG}_pmc_$C.err)
+  (cd /tmp && rocprofv3 --pmc $C --output-format csv -d $OUT/${TAG}_pmc_$C -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline --no-secondary --no-pmc --no-alu-ceiling > /dev/null 2> $OUT/${TAG}_pmc_$C.err)
   f=$(find $OUT/${TAG}_pmc_$C -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python tools/pmc_summary.py $f $C | tee $OUT/${TAG}_pmc_$C.txt
 done
