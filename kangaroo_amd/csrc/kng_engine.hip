@@ -367,6 +367,7 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch, InvRing
                 const v16 b0 = xch[(2 * slot) * 64 + col], b1 = xch[(2 * slot + 1) * 64 + col];
                 return fe{{b0.x, b0.y, b1.x, b1.y}};
             };
+#ifdef KNG_INV_ONE_WAVE // measurement builds only (tools/build_variant.sh): round 5's form -- a pair tree, wave 0 inverts alone
             if (w >= 2) put(w, acc);
             __syncthreads();
             fe pb = fe_one(), pre = fe_one(), i = fe_one();
@@ -376,10 +377,6 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch, InvRing
                 put(w, pre);
             }
             __syncthreads();
-            // ONE inversion, on two waves (kng_modinv.h): wave 0 leads -- division steps and f, g --, wave 1 follows one
-            // round behind with d, e and ends up holding t = 1 / (pre0 * pre1).  Round 5: wave 0 alone, waves 1-3 at the
-            // barrier: the 64 inversions of a launch of such a herd ARE the launch (1.91 ms of 1.91 ms at 65 536 kangaroos).
-#ifdef KNG_INV_ONE_WAVE // measurement builds only (tools/build_variant.sh): round 5's form, wave 0 inverts alone
             if (w == 0) {
                 const fe q1 = get(1);
                 const fe t = fe_inv(fe_mul(pre, q1));
@@ -388,24 +385,40 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch, InvRing
             }
             __syncthreads();
             if (w == 1) i = get(1);
-#else
-            if (w == 0) {
-                fe_inv_lead(fe_mul(pre, get(1)), ring);
-            } else if (w == 1) {
-                const fe t = fe_inv_follow(ring);
-                const fe p0 = get(0);
-                put(0, fe_mul(t, pre)); // 1/pre0 (pre = this wave's own pair product)
-                i = fe_mul(t, p0);      // 1/pre1
-            }
-            __syncthreads();
-            if (w == 0) i = get(0);
-#endif
             if (w < 2) {
                 put(w + 2, fe_mul(i, acc)); // 1/pb
                 inv = fe_mul(i, pb);        // 1/acc
             }
             __syncthreads();
             if (w >= 2) inv = get(w);
+#else
+            // Round 6.  (i) ONE inversion on two waves (kng_modinv.h): wave 0 leads -- division steps and f, g --, wave 1 follows
+            // one round behind with d, e and ends up holding t = 1 / (a0 a1 a2 a3).  Round 5: wave 0 alone, waves 1-3 at the
+            // barrier: the 64 inversions of a launch of such a herd ARE the launch (1.91 ms of 1.91 ms at 65 536 kangaroos).
+            // (ii) What follows the inversion is ONE multiplication per wave: every wave has multiplied the products of the
+            // OTHER three together while it had nothing to do (round 5 and the first form of this round walked the pair tree
+            // back: two multiplications on the follower, a barrier, two on waves 0 and 1, a barrier -- all of it serial latency).
+            put(w, acc);
+            __syncthreads();
+            const fe a0 = get(0), a1 = get(1), a2 = get(2), a3 = get(3);
+            fe p01 = fe_one();
+            if (w == 0) put(4, p01 = fe_mul(a0, a1));
+            if (w == 2) put(5, fe_mul(a2, a3));
+            __syncthreads();
+            fe others; // the product of the other three waves' products
+            if (w == 0) {
+                const fe p23 = get(5);
+                fe_inv_lead(fe_mul(p01, p23), ring);
+                others = fe_mul(a1, p23); // (while the follower finishes)
+            } else if (w == 1) {
+                others = fe_mul(a0, get(5)); // (while the lead runs its first division steps)
+                put(6, fe_inv_follow(ring));
+            } else {
+                others = fe_mul(get(4), w == 2 ? a3 : a2);
+            }
+            __syncthreads();
+            inv = fe_mul(get(6), others); // 1 / acc
+#endif
             if (G == 0) continue;
         } else {
             inv = fe_inv(acc);
@@ -488,7 +501,7 @@ KNG_DEV void walk_body(const WalkArgs &a, const uint64_t *tab, v16 *xch, InvRing
 template <int SHARE, bool DSPLIT, bool ASM>
 __global__ void __launch_bounds__(SHARE == 8 ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2, 2))) kng_walk_share_kernel(const WalkArgs a) {
     __shared__ uint64_t tab[JT_WORDS];
-    __shared__ v16 xch[SHARE == 8 ? 1024 : SHARE == 4 ? 512 : 1];
+    __shared__ v16 xch[SHARE == 8 ? 1024 : SHARE == 4 ? 1024 : 1]; // share 4: seven 64-lane slots of one field element (4 products, p01, p23, t)
     // share 4: the matrices the two waves of an inversion hand over (20 KB); the other forms get a word
     __shared__ typename std::conditional<SHARE == 4, InvRing, uint32_t>::type ring_mem;
     InvRing *const ring = reinterpret_cast<InvRing *>(&ring_mem);
