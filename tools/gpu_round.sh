@@ -5,7 +5,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-echo "== pytest -m gpu"; python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee $OUT/${TAG}_pytest_gpu.txt
+echo "== pytest -m gpu"; python -m pytest tests -m gpu -x -q --durations=15 2>&1 | tail -26 | tee $OUT/${TAG}_pytest_gpu.txt
 echo "== smoke"; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/${TAG}_smoke.txt
 if [ -x oracle/_ref/kangaroo_hip ]; then
   echo "== reference program on our engine: kangaroo -gpu -check (Check.cpp:467-621)"
