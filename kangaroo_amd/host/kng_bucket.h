@@ -50,14 +50,10 @@ inline uint32_t split_avg_knob() {
     const long v = e ? atol(e) : 8;
     return (uint32_t)(v < 2 ? 2 : v > 4096 ? 4096 : v); // k_for() halves it: below 2 every bucket would split without end
 }
-inline uint32_t split_avg() {
-    static const uint32_t v = split_avg_knob();
-    return v;
-}
-inline bool grow2() { // runs grow by doubling instead of by size class (measurement knob)
-    static const bool v = getenv("KNGT_GROW2") && atoi(getenv("KNGT_GROW2"));
-    return v;
-}
+inline const uint32_t SPLIT_AVG = split_avg_knob(); // (C++17 inline variables: one object for every translation unit, no guard in the hot path)
+inline const bool GROW2 = getenv("KNGT_GROW2") && atoi(getenv("KNGT_GROW2")); // runs grow by doubling instead of by size class (measurement knob)
+inline uint32_t split_avg() { return SPLIT_AVG; }
+inline bool grow2() { return GROW2; }
 constexpr uint8_t K_MAX = 24;
 
 inline int cmp_x(const uint64_t a[2], const uint64_t b[2]) {

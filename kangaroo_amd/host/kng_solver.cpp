@@ -702,32 +702,51 @@ void worker_main(kngs_solver *s, Worker *w) {
     }
 }
 
-// upload the first `count` kangaroos of worker w from the open work file, in chunks
-int upload_from_file(kngs_solver *s, Worker *w, uint64_t count) {
-    const uint64_t C = 1u << 16;
-    std::vector<uint64_t> x(C * 4), y(C * 4), d(C * 4), dd(C * 2);
-    for (uint64_t c0 = 0; c0 < count; c0 += C) {
-        const uint64_t m = count - c0 < C ? count - c0 : C;
-        if (kngw_get_kangaroos(s->herd_file, x.data(), y.data(), d.data(), m) != 0) return fail("%s", kngw_last_error());
-        // device distances: odd (wild) indices carry +wildOffset mod n (GPUEngine.cu:406-411); c0 is even
-        if (kngh_to_device_distances(d.data(), m, s->wild_offset.v, dd.data()) != 0) return fail("restored distance does not fit 128 bits");
-        if (kng_set_kangaroos_range(w->eng, c0, m, x.data(), 4, y.data(), 4, dd.data(), 2) != KNG_OK)
-            return fail("kng_set_kangaroos_range: %s", kng_last_error());
+// a pinned buffer of `piece` work-file records for streaming between a file and an engine's snapshot buffer (pageable when
+// the driver refuses: slower copies, same result)
+struct RecordStage {
+    static constexpr uint64_t piece = 1u << 18; // 24 MB
+    uint8_t *buf = nullptr;
+    bool pinned = false;
+    RecordStage() {
+        buf = static_cast<uint8_t *>(kng_alloc_pinned(piece * 96));
+        pinned = buf != nullptr;
+        if (!buf) buf = static_cast<uint8_t *>(std::malloc(piece * 96));
     }
+    ~RecordStage() {
+        if (pinned) kng_free_pinned(buf);
+        else std::free(buf);
+    }
+};
+
+// upload the first `count` kangaroos of worker w from the open work file: the file's 96-byte records go to the device as they
+// are and ONE kernel turns them into herd state, the wild offset added mod n (kng_snapshot_write / kng_snapshot_restore;
+// rounds 3-5 converted every kangaroo on the host and uploaded x, y, d planes through kng_set_kangaroos_range)
+int upload_from_file(kngs_solver *s, Worker *w, uint64_t count) {
+    RecordStage st;
+    if (!st.buf) return fail("out of memory");
+    for (uint64_t c0 = 0; c0 < count; c0 += RecordStage::piece) {
+        const uint64_t m = count - c0 < RecordStage::piece ? count - c0 : RecordStage::piece;
+        if (kngw_get_records(s->herd_file, st.buf, m) != 0) return fail("%s", kngw_last_error());
+        if (kng_snapshot_write(w->eng, c0, m, st.buf) != KNG_OK) return fail("kng_snapshot_write: %s", kng_last_error());
+    }
+    uint64_t bad = 0;
+    if (kng_snapshot_restore(w->eng, 0, count, s->wild_offset.v, &bad) != KNG_OK) return fail("restored distance does not fit 128 bits: %s", kng_last_error());
+    (void)kng_snapshot_release(w->eng); // a save brings the buffer back
     s->herd_left -= count;
     s->herd_loaded += count;
     return 0;
 }
 
-int dump_herd(kngs_solver *s, Worker *w, kngw_file *f) {
-    const uint64_t C = 1u << 16;
-    std::vector<uint64_t> x(C * 4), y(C * 4), d(C * 4), dd(C * 2);
-    for (uint64_t c0 = 0; c0 < w->n; c0 += C) {
-        const uint64_t m = w->n - c0 < C ? w->n - c0 : C;
-        if (kng_get_kangaroos_range(w->eng, c0, m, x.data(), 4, y.data(), 4, dd.data(), 2) != KNG_OK)
-            return fail("kng_get_kangaroos_range: %s", kng_last_error());
-        kngh_to_true_distances(dd.data(), nullptr, m, s->wild_offset.v, d.data()); // c0 even: parity by position
-        if (kngw_put_kangaroos(f, x.data(), y.data(), d.data(), m) != 0) return fail("%s", kngw_last_error());
+// the herd of worker w as the engine's last snapshot holds it -> the kangaroo section of f.  May run while the worker walks
+// on (kng_snapshot_read is the one call of the engine's C ABI another host thread may make meanwhile).
+int dump_herd(Worker *w, kngw_file *f) {
+    RecordStage st;
+    if (!st.buf) return fail("out of memory");
+    for (uint64_t c0 = 0; c0 < w->n; c0 += RecordStage::piece) {
+        const uint64_t m = w->n - c0 < RecordStage::piece ? w->n - c0 : RecordStage::piece;
+        if (kng_snapshot_read(w->eng, c0, m, st.buf) != KNG_OK) return fail("kng_snapshot_read: %s", kng_last_error());
+        if (kngw_put_records(f, st.buf, m) != 0) return fail("%s", kngw_last_error());
     }
     return 0;
 }
@@ -1332,18 +1351,24 @@ int kngs_save(kngs_solver *s, const char *path, int with_kangaroos) {
     std::memcpy(h.key_y, s->cfg.key_y, 32);
     h.total_count = st.jumps;
     h.total_seconds = st.seconds;
-    kngw_file *f = kngw_create(path, &h, s->table, with_kangaroos ? st.kangaroos : 0);
-    if (!f) {
-        rc = fail("%s", kngw_last_error());
-    } else {
+    // The GPU threads are parked at a launch boundary and every queued point is in the table.  Each engine freezes its herd as
+    // work-file records in its second device buffer (one kernel, kng_snapshot); header and table are written; then the GPU
+    // threads are RELEASED and the kangaroo section is streamed from the snapshots while they walk on (rounds 3-5 kept every
+    // GPU parked until the last kangaroo was on disk: 0.26 s per GPU at the default herd, one GPU after the other).
+    if (with_kangaroos)
+        for (Worker *w : s->workers)
+            if (rc == 0 && kng_snapshot(w->eng, s->wild_offset.v) != KNG_OK) rc = fail("kng_snapshot(gpu %d): %s", w->dev, kng_last_error());
+    kngw_file *f = rc == 0 ? kngw_create(path, &h, s->table, with_kangaroos ? st.kangaroos : 0) : nullptr;
+    if (rc == 0 && !f) rc = fail("%s", kngw_last_error());
+    release_workers(s);
+    if (f) {
         if (with_kangaroos)
             for (Worker *w : s->workers)
-                if (rc == 0) rc = dump_herd(s, w, f); // the worker threads are parked: the engines are ours
+                if (rc == 0) rc = dump_herd(w, f);
         const std::string keep = g_err;
         if (kngw_close(f) != 0 && rc == 0) rc = fail("%s", kngw_last_error());
         else if (rc != 0) g_err = keep;
     }
-    release_workers(s);
     return rc;
 }
 

@@ -91,6 +91,22 @@ int kngw_put_kangaroos(kngw_file *w, const uint64_t *x, const uint64_t *y, const
     return 0;
 }
 
+int kngw_put_records(kngw_file *w, const void *records, uint64_t n) {
+    if (!w || !w->writer || (!records && n)) return fail("bad argument"), -1;
+    if (w->done + n > w->declared) return fail("%s: more kangaroos than the %llu announced", w->path.c_str(), (unsigned long long)w->declared), -1;
+    if (n && std::fwrite(records, 96, n, w->f) != n) return fail("short write to %s: %s", w->path.c_str(), std::strerror(errno)), -1;
+    w->done += n;
+    return 0;
+}
+
+int kngw_get_records(kngw_file *r, void *records, uint64_t n) {
+    if (!r || r->writer || (!records && n)) return fail("bad argument"), -1;
+    if (r->done + n > r->declared) return fail("%s holds only %llu kangaroos", r->path.c_str(), (unsigned long long)r->declared), -1;
+    if (n && std::fread(records, 96, n, r->f) != n) return fail("%s: truncated kangaroo section", r->path.c_str()), -1;
+    r->done += n;
+    return 0;
+}
+
 kngw_file *kngw_open(const char *path, kngw_header *h, kngt_table *table, uint64_t *n_kangaroos) {
     if (!path || !h) return (kngw_file *)fail("null argument");
     FILE *f = std::fopen(path, "rb");

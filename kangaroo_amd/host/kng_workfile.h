@@ -45,6 +45,10 @@ typedef struct kngw_file kngw_file;
 kngw_file *kngw_create(const char *path, const kngw_header *h, const kngt_table *table, uint64_t n_kangaroos);
 /* append n kangaroos: x, y, d_true are n x 4 limbs each */
 int kngw_put_kangaroos(kngw_file *f, const uint64_t *x, const uint64_t *y, const uint64_t *d_true, uint64_t n);
+/* the same from / into n records of the file's own layout -- 96 bytes each: x[4], y[4], d_true[4] -- as the engine's
+ * kng_snapshot_read delivers and kng_snapshot_write takes them (no per-kangaroo copy on the host) */
+int kngw_put_records(kngw_file *f, const void *records, uint64_t n);
+int kngw_get_records(kngw_file *f, void *records, uint64_t n);
 
 /* ---- reader.  Fills *h; loads the hash table into table when the file has one and table != NULL
  * (skips it otherwise); *n_kangaroos = size of the kangaroo section. */
