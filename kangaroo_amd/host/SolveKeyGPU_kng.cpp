@@ -49,6 +49,7 @@
 #include "kng_hashtable_ext.h"
 #include "kng_host.h"
 #include "kng_ingest.h"
+#include "kng_placement.h"
 #include "kng_savework.h"
 
 #ifndef WITHGPU
@@ -80,6 +81,19 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
     return;
   }
   const int thId = ph->threadId;
+
+  // On a machine with several NUMA nodes this thread belongs next to its GPU: the pinned ring it reads (allocated by the
+  // engine it is about to create: first touch) was written over that node's PCIe root.  KNG_TABLE_PIN=0 leaves it alone.
+  {
+    const char *mode = getenv("KNG_TABLE_PIN");
+    if (!(mode && (!strcmp(mode, "0") || !strcmp(mode, "off")))) {
+      const std::vector<cpu_set_t> nodes = kng_placement::numa_node_cpus();
+      int usable = 0;
+      for (const cpu_set_t &c : nodes) usable += CPU_COUNT(&c) > 0;
+      const int node = kng_device_numa_node(ph->gpuId);
+      if (usable > 1 && kng_placement::node_usable(nodes, node)) (void)kng_placement::pin_this_thread(nodes[(size_t)node], "GPU");
+    }
+  }
 
   GPUEngine *gpu = new GPUEngine(ph->gridSizeX, ph->gridSizeY, ph->gpuId, 65536 * 2);
   kng_engine *eng = kng_shim_engine(gpu);
@@ -223,8 +237,9 @@ void Kangaroo::SolveKeyGPU(TH_PARAM *ph) {
     Ingest ingest(&hashTable, off, poolThreads, maxChunks);
     if (keyIdx == 0) // what the table side can take, next to what the kernel will offer (INTEGRATION.md has the table of -d)
       ::printf("SolveKeyGPU Thread GPU#%d: 2^%.1f points per launch at DP %d into a pool of %d table thread%s (%d per GPU thread, "
-               "KNG_TABLE_THREADS; one thread takes ~10 M points/s)\n",
-               ph->gpuId, perLaunch ? log2((double)perLaunch) : 0.0, bits, ingest.threads(), ingest.threads() == 1 ? "" : "s", tableThreads);
+               "KNG_TABLE_THREADS; one thread takes ~10 M points/s)%s\n",
+               ph->gpuId, perLaunch ? log2((double)perLaunch) : 0.0, bits, ingest.threads(), ingest.threads() == 1 ? "" : "s", tableThreads,
+               ingest.nodes_used() > 1 ? ", spread over the NUMA nodes (KNG_TABLE_PIN)" : "");
 
     const bool refSave = getenv("KNG_REF_SAVE") != NULL, verifySave = getenv("KNG_SAVE_VERIFY") != NULL;
     vector<Event> events;

@@ -27,7 +27,10 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include "kng_hashtable_ext.h"
+#include "kng_placement.h"
 
 namespace kng_ingest {
 
@@ -81,7 +84,24 @@ class Pool {
   Pool(HashTable *table, const uint64_t wild_off[2], int threads) : ht(table), W(threads < 1 ? 1 : threads), workers((size_t)W) {
     off[0] = wild_off[0];
     off[1] = wild_off[1];
+    // On a machine with several NUMA nodes (eight GPUs hang off two sockets) table thread w of W is confined to the CPUs of
+    // node w * nodes / W: the memory of its buckets -- first touched by it -- stays local for the whole run, as in the repo's
+    // own solver (kng_placement.h).  KNG_TABLE_PIN=core: one physical core each; KNG_TABLE_PIN=0: no confinement.  A machine
+    // with one usable node is left alone.
+    const char *mode = getenv("KNG_TABLE_PIN");
+    if (!(mode && (!strcmp(mode, "0") || !strcmp(mode, "off"))))
+      plan = kng_placement::plan_consumers(kng_placement::numa_node_cpus(), W, mode && !strcmp(mode, "core"), (unsigned)getpid());
     for (int w = 0; w < W; w++) workers[(size_t)w].th = std::thread([this, w] { run(w); });
+  }
+  // NUMA nodes the table threads were spread over (0: not confined)
+  int nodes_used() const {
+    int used = 0, last = -1;
+    for (const kng_placement::Placement &p : plan)
+      if (p.pin && p.node != last) {
+        used++;
+        last = p.node;
+      }
+    return used;
   }
   ~Pool() {
     for (Worker &w : workers) {
@@ -148,6 +168,7 @@ class Pool {
     return r;
   }
   void run(int id) {
+    if ((size_t)id < plan.size() && plan[(size_t)id].pin) (void)kng_placement::pin_this_thread(plan[(size_t)id].cpus, "table");
     Worker &w = workers[(size_t)id];
     std::vector<kng_ht_event> ev(CHUNK);
     for (;;) {
@@ -215,6 +236,7 @@ class Pool {
   uint64_t off[2];
   const int W;
   std::vector<Worker> workers;
+  std::vector<kng_placement::Placement> plan;
   std::mutex spare_m;
   std::vector<Chunk *> spare;
 };
@@ -236,6 +258,7 @@ class Ingest {
     me.idle.wait(l, [this] { return me.outstanding == 0; });
   }
   int threads() const { return pool->threads(); }
+  int nodes_used() const { return pool->nodes_used(); }
   // Copy `n` records into the chunks of their owners and hand the chunks over; blocks while too many of this producer's chunks
   // wait.  Returns the seconds spent blocked.  `tag` goes into the `reserved` word of every copied record (the table does not
   // look at it): events carry it back, which lets the caller tell which launch a point came from.

@@ -63,6 +63,11 @@ int main(int argc, char **argv) {
   std::vector<double> busy((size_t)P, 0.0), blocked((size_t)P, 0.0);
   std::vector<std::thread> th;
   printf("# HashTable_kng.o behind kng_ingest.h: %d owner-partitioned table threads, %d producers, %u points per push\n", W, P, per_push);
+  {
+    /* where the table threads run: each reports the CPUs it may use once it has started (kng_placement.h; KNG_TABLE_PIN) */
+    kng_ingest::Ingest probe(ht, off2, W, 64);
+    printf("# table threads spread over %d NUMA node(s)%s\n", probe.nodes_used(), probe.nodes_used() ? "" : " (not confined)");
+  }
   printf("# %12s %14s %22s %10s\n", "entries", "points/s", "ns/point/table-thread", "rss MB");
   std::atomic<int> alive{P};
   std::vector<std::atomic<uint64_t>> busy_ns((size_t)P), done_pts((size_t)P);

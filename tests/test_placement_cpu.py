@@ -190,3 +190,27 @@ def test_sampler_survives_a_library_without_the_power_symbols():
 
     assert t._power_w(Bare(), 0) is None and t._sclk_mhz(Bare(), 0) is None and t._energy_j(Bare(), 0) is None
     assert t.smi_bdfs(Bare()) == []
+
+
+def test_table_threads_of_the_reference_program_are_spread_over_the_nodes(tmp_path, allowed):
+    """Round 6: the pool of owner-partitioned table threads behind SolveKeyGPU_kng.cpp (kng_ingest.h) uses the same placement
+    as the repo's solver: on a made-up two-node tree (this process's CPUs cut in two) the pool says two nodes, on a one-node
+    tree and with KNG_TABLE_PIN=0 it confines nothing -- and the points all arrive either way."""
+    from helpers import ref_binary
+
+    exe = ref_binary("poolbench")
+    half = len(allowed) // 2
+    two = _tree(tmp_path / "two", {0: _cpulist(allowed[:half]), 1: _cpulist(allowed[half:])})
+    one = _tree(tmp_path / "one", {0: _cpulist(allowed)})
+
+    def run(root, **env):
+        e = dict(os.environ, KNG_SYSFS_ROOT=root, **env)
+        out = subprocess.run([exe, "200000", "100000", "4", "2", "20000"], capture_output=True, text=True, timeout=300, env=e)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "# 200000 entries in " in out.stdout, out.stdout
+        return out.stdout
+
+    assert "table threads spread over 2 NUMA node(s)" in run(two)
+    assert "table threads spread over 0 NUMA node(s) (not confined)" in run(one)
+    assert "table threads spread over 0 NUMA node(s) (not confined)" in run(two, KNG_TABLE_PIN="0")
+    assert "table threads spread over 2 NUMA node(s)" in run(two, KNG_TABLE_PIN="core")
