@@ -515,7 +515,16 @@ int kng_ht_ingest(HashTable *ht, const kng_dp_record *recs, uint32_t n, const ui
     const unsigned __int128 off = ((unsigned __int128)wild_off[1] << 64) | wild_off[0];
     // three look-ahead stages turn the dependent misses of one insertion (bucket header -> run header -> run) into
     // independent misses of different insertions.  The reads ahead of the lock are hints only (kng_bucket::prefetch).
-    constexpr uint32_t A = 24, B = 16, C = 8;
+    // (KNG_HT_LOOKAHEAD="A,B,C": measurement knob, points of look-ahead per stage)
+    static const struct Look {
+        uint32_t a = 24, b = 16, c = 8;
+        Look() {
+            unsigned x, y, z;
+            const char *e = getenv("KNG_HT_LOOKAHEAD");
+            if (e && sscanf(e, "%u,%u,%u", &x, &y, &z) == 3 && x >= y && y >= z && x <= 4096) a = x, b = y, c = z;
+        }
+    } look;
+    const uint32_t A = look.a, B = look.b, C = look.c;
     for (uint32_t i = 0; i < n + A; i++) {
         if (i < n) kng_bucket::prefetch(p->bk[recs[i].x[2] & HASH_MASK], recs[i].x[1], 0);
         if (i >= A - B && i - (A - B) < n) kng_bucket::prefetch(p->bk[recs[i - (A - B)].x[2] & HASH_MASK], recs[i - (A - B)].x[1], 1);
